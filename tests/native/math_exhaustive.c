@@ -1,0 +1,129 @@
+/*
+ * Exhaustive / sampled comparison of ppf_math.h against the host libm.
+ * Test infrastructure only.
+ *
+ *   math_exhaustive acosf  STRIDE   all floats i*STRIDE: pm_acosf vs acosf
+ *   math_exhaustive atanf  STRIDE   all floats i*STRIDE: pm_atanf vs atanf
+ *   math_exhaustive atan2f N        N pseudo-random + structured (y,x) pairs
+ *   math_exhaustive quant  N        pm_quant_down_pos vs x - fmodf(x, step)
+ *
+ * Prints "mismatches=K checked=N" and exits non-zero when K != 0.
+ * NaN results compare equal when both are NaN (payload is canonicalised by the
+ * caller of pm_acosf; see ppf_math.h).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ppf_math.h"
+
+static uint64_t splitmix(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+static int same(float a, float b)
+{
+    if (isnan(a) && isnan(b)) return 1;
+    return PM_BITS_F2U(a) == PM_BITS_F2U(b);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    const char *mode = argv[1];
+    uint64_t arg = strtoull(argv[2], 0, 10);
+    uint64_t bad = 0, checked = 0;
+
+    if (!strcmp(mode, "acosf") || !strcmp(mode, "atanf")) {
+        int is_acos = !strcmp(mode, "acosf");
+        uint64_t n = (1ull << 32) / arg;
+#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+        for (uint64_t i = 0; i < n; i++) {
+            float x = PM_BITS_U2F((uint32_t)(i * arg));
+            float a = is_acos ? pm_acosf(x) : pm_atanf(x);
+            float b = is_acos ? acosf(x) : atanf(x);
+            checked++;
+            if (!same(a, b)) {
+                bad++;
+                if (bad < 5) fprintf(stderr, "%s(%a): pm=%a libm=%a\n", mode, x, a, b);
+            }
+        }
+    } else if (!strcmp(mode, "atan2f")) {
+#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+        for (uint64_t i = 0; i < arg; i++) {
+            uint64_t s = i * 0x2545f4914f6cdd1dull + 12345;
+            uint64_t r = splitmix(&s);
+            float y, x;
+            switch (i & 3) {
+            case 0: /* arbitrary bit patterns */
+                y = PM_BITS_U2F((uint32_t)r);
+                x = PM_BITS_U2F((uint32_t)(r >> 32));
+                break;
+            case 1: { /* moderate magnitudes, the regime the vote path lives in */
+                y = (float)((double)(int32_t)(uint32_t)r / 2147483648.0 * 4.0);
+                x = (float)((double)(int32_t)(uint32_t)(r >> 32) / 2147483648.0 * 4.0);
+                break;
+            }
+            case 2: { /* ratios near the atanf range-reduction thresholds */
+                static const float thr[5] = {0.4375f, 0.6875f, 1.1875f, 2.4375f, 1.0f};
+                x = (float)((double)(uint32_t)r / 4294967296.0 + 0.01);
+                if (r >> 63) x = -x;
+                y = x * thr[(r >> 40) % 5];
+                y = PM_BITS_U2F(PM_BITS_F2U(y) + (uint32_t)((r >> 32) & 7) - 3);
+                if ((r >> 62) & 1) y = -y;
+                break;
+            }
+            default: { /* zeros, infinities, huge exponent gaps */
+                static const uint32_t sp[8] = {0x00000000u, 0x80000000u, 0x7f800000u, 0xff800000u,
+                                               0x3f800000u, 0x00000001u, 0x7f7fffffu, 0x5d5e0b6bu};
+                y = PM_BITS_U2F(sp[r & 7]);
+                x = PM_BITS_U2F(((r >> 8) & 1) ? sp[(r >> 3) & 7] : (uint32_t)(r >> 32));
+                break;
+            }
+            }
+            float a = pm_atan2f(y, x), b = atan2f(y, x);
+            checked++;
+            if (!same(a, b)) {
+                bad++;
+                if (bad < 5) fprintf(stderr, "atan2f(%a,%a): pm=%a libm=%a\n", y, x, a, b);
+            }
+        }
+    } else if (!strcmp(mode, "quant")) {
+#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+        for (uint64_t i = 0; i < arg; i++) {
+            uint64_t s = i * 0x9e3779b97f4a7c15ull + 777;
+            uint64_t r = splitmix(&s);
+            float step, x;
+            int k;
+            if (i & 1) {
+                step = PM_D_ANGLE;
+                x = (float)((double)(uint32_t)r / 4294967296.0 * 6.2831856);
+            } else {
+                step = (float)((double)(uint32_t)(r >> 32) / 4294967296.0 * 0.3 + 1e-3);
+                x = (float)((double)(uint32_t)r / 4294967296.0) * step * (float)((r >> 20) % 3000);
+            }
+            if ((i % 1000) == 0) { /* exact multiples: the boundary cases */
+                x = step * (float)((r >> 8) % 64);
+            }
+            float inv = 1.0f / step;
+            float a = pm_quant_down_pos(x, step, inv, &k);
+            float b = x - fmodf(x, step);
+            checked++;
+            if (k < 0) continue;
+            if (!same(a, b)) {
+                bad++;
+                if (bad < 5) fprintf(stderr, "quant(%a,%a): pm=%a libm=%a\n", x, step, a, b);
+            }
+        }
+    } else {
+        return 2;
+    }
+    printf("mismatches=%llu checked=%llu\n", (unsigned long long)bad, (unsigned long long)checked);
+    return bad != 0;
+}
