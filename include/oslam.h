@@ -1,0 +1,182 @@
+/*
+ * oslam.h -- C-ABI of the MI355X-native PPF registration path
+ * (liboslam_hip.so).  Plain C: opaque handles, plain pointers and sizes, every
+ * function returns an int status (0 = OSLAM_OK).  Nothing here exits the
+ * process (the reference's HANDLE_ERROR does, include/impl/util.hpp:18-26).
+ *
+ * Each entry point names the reference interface it replaces; paths are
+ * relative to the reference's pcl/alignment/.  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Clouds are passed as two float pointers (first coordinate of the first
+ * point, first component of the first normal) plus a byte stride between
+ * consecutive points, so a pcl::PointCloud<pcl::PointNormal> (48-byte points,
+ * xyz at +0, normal at +16) is passed without a copy:
+ *     xyz = &cloud[0].x, nrm = &cloud[0].normal_x, stride_bytes = 48.
+ * Tightly packed float[n][3] arrays use stride_bytes = 12.  Host pointers.
+ */
+#ifndef OSLAM_H
+#define OSLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSLAM_OK 0
+#define OSLAM_E_INVALID 1     /* bad argument (NULL, n == 0, d_dist <= 0, mismatching d_dist ...) */
+#define OSLAM_E_DEVICE 2      /* HIP error; see oslam_last_error() */
+#define OSLAM_E_NOMEM 3
+#define OSLAM_E_NO_VOTES 4    /* no scene pair matched the model: T is all zeros */
+#define OSLAM_E_LIMIT 5       /* cloud exceeds an encoding limit (see oslam_model_create) */
+
+/* Per-vote arithmetic of the alpha angle (reference src/cuda/kernel.cu:302-342). */
+#define OSLAM_VOTE_EXACT 0    /* same float operations as the reference: identical accumulator */
+#define OSLAM_VOTE_FAST 1     /* alpha = alpha_scene - alpha_model (Drost): 8-byte model entries */
+
+/* Flags of the reference's CLI that reach the path (src/alignment.cpp:119-172)
+ * plus this build's extensions.  oslam_params_default() fills the reference's
+ * defaults. */
+typedef struct oslam_params {
+    unsigned ref_point_df;         /* --ref_point_df, default 1 */
+    float vote_count_threshold;    /* --vote_count_threshold, default 0.4 */
+    int cpu_clustering;            /* --cpu_clustering, default 0 */
+    int use_l1_norm;               /* --use_l1_norm, default 0 */
+    int use_averaged_clusters;     /* --use_averaged_clusters, default 0 */
+    int dev;                       /* --dev: device = min(numDevices-1, dev) (src/cuda/ppf.cu:45); default 0 */
+    /* extensions */
+    int vote_mode;                 /* OSLAM_VOTE_EXACT (default) or OSLAM_VOTE_FAST */
+    int shard_rank;                /* scene reference points r = df*(rank + world*t); default 0 */
+    int shard_world;               /* default 1 */
+    unsigned max_cells;            /* capacity of the peak-record buffer, default 1<<22 */
+    int reserved[6];
+} oslam_params;
+
+/* Counters the reference logs at debug level (model.cu:122,152,161-168;
+ * util.hpp:46) plus timings; all exact integers. */
+typedef struct oslam_stats {
+    uint64_t num_scene_ppfs;       /* valid ordered scene pairs (reference point r, i != r) on this shard */
+    uint64_t num_hits;             /* of those, pairs whose key is in the model table */
+    uint64_t num_votes;            /* accumulator increments = num_nonunique_votes */
+    uint64_t num_unique_votes;     /* non-empty accumulator cells */
+    uint64_t num_model_keys;       /* num_bins of the model table (counts the key-0 self-pair bucket) */
+    uint64_t num_top;              /* cells with count > threshold * max */
+    uint32_t max_count;            /* largest cell */
+    uint32_t num_emitted;          /* records the vote kernel wrote before the final filter */
+    float ms_vote;                 /* vote kernel(s), HIP events on the launch stream */
+    float ms_total;                /* whole oslam_align call, host clock */
+    uint32_t vote_launches;
+    uint32_t reserved[5];
+} oslam_stats;
+
+/* One accumulator peak: code = s_r << 32 | m_r << 6 | alpha_idx (kernel.cu:549). */
+typedef struct oslam_cell {
+    uint64_t code;
+    uint32_t count;
+    uint32_t pad;
+} oslam_cell;
+
+typedef struct oslam_model oslam_model;
+typedef struct oslam_scene oslam_scene;
+
+/* Reference defaults (src/alignment.cpp:119-172). */
+int oslam_params_default(oslam_params *p);
+
+/* d_dist = tau_d * max bounding-box extent (src/alignment.cpp:246-253). */
+int oslam_d_dist_from_cloud(const float *xyz, size_t n, size_t stride_bytes, float tau_d,
+                            float *d_dist_out);
+
+/* Model::Model (include/model.h:17-19, src/cuda/model.cu:43-82): uploads the
+ * cloud, computes all M*(M-1) pair features and builds the HBM-resident hash
+ * table.  Limits: 2 <= n <= 46340 (the reference's own 32-bit pair index,
+ * kernel.cu:433).  params may be NULL (defaults). */
+int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
+                       float d_dist, const oslam_params *params, oslam_model **out);
+void oslam_model_destroy(oslam_model *m);
+
+/* Model::SetModelPointVoteWeights (include/model.h:22); weights[n], default all 1. */
+int oslam_model_set_point_weights(oslam_model *m, const float *weights, size_t n);
+
+/* Scene::Scene (include/scene.h:15-16, src/cuda/scene.cu:24-55).  d_dist must
+ * equal the d_dist of the model it is aligned with (src/cuda/ppf.cu:64-67). */
+int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
+                       float d_dist, unsigned ref_point_downsample_factor,
+                       const oslam_params *params, oslam_scene **out);
+void oslam_scene_destroy(oslam_scene *s);
+
+/* Model::ppf_lookup + result extraction (model.cu:269-306, ppf.cu:74-93):
+ * T_rowmajor receives the best model->scene pose.  stats may be NULL. */
+int oslam_align(oslam_model *m, oslam_scene *s, float T_rowmajor[16], oslam_stats *stats);
+
+/* ppf_registration (include/ppf.h:9-15, src/cuda/ppf.cu:29-106): every scene
+ * against every model; T_out[(i*n_models + j)*16 ..] = pose of model j in
+ * scene i.  model_weights is accepted and ignored, as in the reference
+ * (ppf.cu:35).  Unlike the reference this does not reset the device. */
+int oslam_ppf_registration(const float *const *scene_xyz, const float *const *scene_nrm,
+                           const size_t *scene_n, size_t n_scenes, const float *const *model_xyz,
+                           const float *const *model_nrm, const size_t *model_n, size_t n_models,
+                           size_t stride_bytes, const float *model_d_dists,
+                           unsigned ref_point_downsample_factor, float vote_count_threshold,
+                           int cpu_clustering, int use_l1_norm, int use_averaged_clusters, int devUse,
+                           const float *model_weights, float *T_out);
+
+/* ht_dist (include/linalg.h:7, src/cuda/linalg.cu:9-20): out = {|dt|, |angle|}. */
+int oslam_ht_dist(const float A[16], const float B[16], float out[2]);
+
+/* ---- host stage (no GPU needed): accumulator peaks -> poses -> clustering.
+ * Counterparts: trans_calc_kernel2, vote_weight_kernel, mat2transquat_kernel,
+ * trans2idx_kernel, rot_clustering_kernel (src/cuda/kernel.cu:605-782),
+ * Model::ClusterTransformations / ClusterTransformationsCPU (src/cuda/model.cu:202-266),
+ * clusterPoses (src/transformation_clustering.cpp:62-137), extraction (src/cuda/ppf.cu:74-93).
+ * xyz/nrm here are packed float[n][3]. */
+void oslam_build_T_g(const float p[3], const float n[3], float T_rowmajor[16]);
+void oslam_sort_cells(oslam_cell *cells, size_t n);                 /* count desc, code asc */
+size_t oslam_filter_cells(oslam_cell *cells, size_t n, float vote_count_threshold, uint32_t max_count);
+int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, const float *m_nrm,
+                     size_t M, const float *s_xyz, const float *s_nrm, size_t S, float d_dist,
+                     int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
+                     const float *model_point_weights, float T_rowmajor[16], float *poses_out);
+
+/* ---- multi-GPU: scene reference points shard across ranks (one process per
+ * GPU).  oslam_align_local runs the vote kernel for this scene's shard
+ * (params.shard_rank/shard_world at oslam_scene_create) and returns up to cap
+ * peak records (count > threshold * local max) in cells_out (host memory) plus
+ * the local maximum; the caller all-gathers records and maxima (RCCL) and every
+ * rank, or rank 0, calls oslam_align_finish on the union. */
+int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, size_t cap,
+                      size_t *n_out, uint32_t *local_max_out, oslam_stats *stats);
+int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, size_t n,
+                       uint32_t global_max, float T_rowmajor[16], oslam_stats *stats);
+
+/* ---- parity taps (tests): values the reference materialises as arrays.
+ * Scene::getHashKeys row r (scene.cu:49-54): keys_out[n] of reference point r,
+ * computed by the GPU key kernel with this d_dist (key 0 on the diagonal). */
+int oslam_scene_keys(oslam_scene *s, size_t ref_index, uint32_t *keys_out);
+int oslam_model_keys(oslam_model *m, size_t ref_index, uint32_t *keys_out);
+/* ParallelHashArray lookup (include/impl/parallel_hash_array.hpp:80-92):
+ * flat pair indices m_r*M + m_i stored under `key`, ascending; returns the
+ * bucket size in *count_out and copies at most cap indices. */
+int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t cap,
+                       size_t *count_out);
+/* Dense accumulator acc[M][32] of scene reference point ref_index after voting. */
+int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uint32_t *acc_out);
+/* Cells kept by the last oslam_align / oslam_align_finish on this model, in
+ * the order (count desc, code asc); poses_out (may be NULL) gets 16 floats per cell. */
+int oslam_last_cells(oslam_model *m, oslam_cell *cells_out, float *poses_out, size_t cap,
+                     size_t *n_out);
+
+/* Launch stream for all kernels of this thread's calls (hipStream_t as void*;
+ * NULL = the default stream).  bench.py passes torch's current stream. */
+int oslam_set_stream(void *hip_stream);
+const char *oslam_last_error(void);
+/* Self-test of the device float path against the host: evaluates pm_acosf /
+ * pm_atan2f / key arithmetic on `n` pseudo-random inputs on both sides and
+ * returns the number of mismatching results in *mismatches. */
+int oslam_selftest_math(size_t n, uint64_t seed, uint64_t *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSLAM_H */

@@ -1,0 +1,826 @@
+/*
+ * oslam_host.c -- the C-ABI of include/oslam.h: host orchestration in C over
+ * the gfx950 kernels of oslam_kernels.hip.
+ *
+ * Mirrors the reference's host layer (pcl/alignment/src/cuda/{ppf,model,scene}.cu)
+ * with two structural differences: nothing N^2-sized is materialised, and a
+ * model's table stays resident in HBM for as many scenes as the caller aligns
+ * (the reference rebuilds scene and model per pair, ppf.cu:57-100).
+ * There is no CPU fallback: every compute call needs the HIP device.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "oslam.h"
+#include "oslam_kernels.h"
+#include "oslam_pose.h"
+#include "ppf_core.h"
+
+static __thread char g_err[512];
+static __thread void *g_stream;
+
+const char *oslam_last_error(void) { return g_err; }
+
+int oslam_set_stream(void *hip_stream)
+{
+    g_stream = hip_stream;
+    return OSLAM_OK;
+}
+
+static int fail(int code, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                 \
+            rc = OSLAM_E_DEVICE;                                                          \
+            goto done;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+#define KCHK(call)                                                                          \
+    do {                                                                                    \
+        int k_ = (call);                                                                    \
+        if (k_ != 0) {                                                                      \
+            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call,                          \
+                     hipGetErrorString((hipError_t)k_), __FILE__, __LINE__);                \
+            rc = OSLAM_E_DEVICE;                                                            \
+            goto done;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* ------------------------------------------------------------------------ */
+int oslam_params_default(oslam_params *p)
+{
+    if (!p) return fail(OSLAM_E_INVALID, "params is NULL");
+    memset(p, 0, sizeof *p);
+    p->ref_point_df = 1;              /* alignment.cpp:134 */
+    p->vote_count_threshold = 0.4f;   /* alignment.cpp:136 */
+    p->cpu_clustering = 0;
+    p->use_l1_norm = 0;
+    p->use_averaged_clusters = 0;
+    p->dev = 0;
+    p->vote_mode = OSLAM_VOTE_EXACT;
+    p->shard_rank = 0;
+    p->shard_world = 1;
+    p->max_cells = 1u << 22;
+    return OSLAM_OK;
+}
+
+int oslam_d_dist_from_cloud(const float *xyz, size_t n, size_t stride_bytes, float tau_d,
+                            float *d_dist_out)
+{
+    float lo[3], hi[3], ext;
+    size_t i;
+    int a;
+    if (!xyz || !d_dist_out || n == 0 || stride_bytes < 12) return fail(OSLAM_E_INVALID, "bad cloud");
+    for (a = 0; a < 3; a++) lo[a] = hi[a] = xyz[a];
+    for (i = 1; i < n; i++) {
+        const float *p = (const float *)((const char *)xyz + i * stride_bytes);
+        for (a = 0; a < 3; a++) {
+            if (p[a] < lo[a]) lo[a] = p[a];
+            if (p[a] > hi[a]) hi[a] = p[a];
+        }
+    }
+    ext = hi[0] - lo[0];
+    if (hi[1] - lo[1] > ext) ext = hi[1] - lo[1];
+    if (hi[2] - lo[2] > ext) ext = hi[2] - lo[2];
+    *d_dist_out = tau_d * ext;        /* alignment.cpp:250-253 */
+    return OSLAM_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+typedef struct cloud_buf {
+    int n;
+    float *h_xyz, *h_nrm;             /* packed [n][3] host copies (pose stage) */
+    float *d_soa;                     /* 6*n floats: px py pz nx ny nz */
+    oslamk_cloud k;
+} cloud_buf;
+
+struct oslam_model {
+    int dev;
+    cloud_buf c;
+    float d_dist, inv_d_dist;
+    oslam_params params;
+    oslamk_table table;
+    oslamk_entry_exact *exact;
+    oslamk_entry_fast *fast;
+    uint32_t n_entries;
+    uint64_t num_model_keys;
+    float *weights;
+    /* align workspace */
+    oslamk_counters *d_counters;
+    oslamk_cell *d_out;
+    uint32_t out_cap;
+    oslam_cell *h_out;
+    /* last result */
+    oslam_cell *last_cells;
+    float *last_poses;
+    size_t n_last;
+    /* host copy of the table for the bucket tap */
+    oslamk_slot *h_slots;
+};
+
+struct oslam_scene {
+    int dev;
+    cloud_buf c;
+    float d_dist;
+    unsigned df;
+    int rank, world;
+    int n_ref;
+    uint32_t *h_ref_idx, *d_ref_idx;
+    float *d_tsg;
+};
+
+static int pick_device(int dev_req, int *dev_out)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(OSLAM_E_DEVICE, "no HIP device available (the PPF path has no CPU fallback)");
+    if (dev_req < 0) dev_req = 0;
+    *dev_out = dev_req < n - 1 ? dev_req : n - 1;     /* ppf.cu:45 */
+    e = hipSetDevice(*dev_out);
+    if (e != hipSuccess) return fail(OSLAM_E_DEVICE, hipGetErrorString(e));
+    return OSLAM_OK;
+}
+
+static void cloud_free(cloud_buf *c)
+{
+    free(c->h_xyz);
+    free(c->h_nrm);
+    if (c->d_soa) (void)hipFree(c->d_soa);
+    memset(c, 0, sizeof *c);
+}
+
+/* AoS with stride -> packed host copies + SoA in HBM (scene.cu:28-40,68-69) */
+static int cloud_upload(cloud_buf *c, const float *xyz, const float *nrm, size_t n, size_t stride)
+{
+    int rc = OSLAM_OK;
+    float *soa = NULL;
+    size_t i;
+    memset(c, 0, sizeof *c);
+    c->n = (int)n;
+    c->h_xyz = (float *)malloc(sizeof(float) * 3 * n);
+    c->h_nrm = (float *)malloc(sizeof(float) * 3 * n);
+    soa = (float *)malloc(sizeof(float) * 6 * n);
+    if (!c->h_xyz || !c->h_nrm || !soa) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    for (i = 0; i < n; i++) {
+        const float *p = (const float *)((const char *)xyz + i * stride);
+        const float *q = (const float *)((const char *)nrm + i * stride);
+        int a;
+        for (a = 0; a < 3; a++) {
+            c->h_xyz[3 * i + a] = p[a];
+            c->h_nrm[3 * i + a] = q[a];
+            soa[(size_t)a * n + i] = p[a];
+            soa[(size_t)(3 + a) * n + i] = q[a];
+        }
+    }
+    HIPCHK(hipMalloc((void **)&c->d_soa, sizeof(float) * 6 * n));
+    HIPCHK(hipMemcpy(c->d_soa, soa, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    c->k.px = c->d_soa;
+    c->k.py = c->d_soa + n;
+    c->k.pz = c->d_soa + 2 * n;
+    c->k.nx = c->d_soa + 3 * n;
+    c->k.ny = c->d_soa + 4 * n;
+    c->k.nz = c->d_soa + 5 * n;
+    c->k.n = (int)n;
+done:
+    free(soa);
+    if (rc != OSLAM_OK) cloud_free(c);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+void oslam_model_destroy(oslam_model *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->dev);
+    cloud_free(&m->c);
+    if (m->table.slots) (void)hipFree(m->table.slots);
+    if (m->exact) (void)hipFree(m->exact);
+    if (m->fast) (void)hipFree(m->fast);
+    if (m->d_counters) (void)hipFree(m->d_counters);
+    if (m->d_out) (void)hipFree(m->d_out);
+    free(m->h_out);
+    free(m->weights);
+    free(m->last_cells);
+    free(m->last_poses);
+    free(m->h_slots);
+    free(m);
+}
+
+int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
+                       float d_dist, const oslam_params *params, oslam_model **out)
+{
+    int rc = OSLAM_OK;
+    oslam_model *m = NULL;
+    uint32_t *d_small = NULL;        /* [0..n_slices) n_unique, then overflow, total, n_first */
+    uint32_t h_small[64 + 3];
+    float *h_tmg = NULL, *d_tmg = NULL;
+    int n_slices, s;
+    uint32_t cap;
+    size_t n_pairs;
+
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (!xyz || !nrm || stride_bytes < 12 || !(d_dist > 0.0f)) return fail(OSLAM_E_INVALID, "bad model arguments");
+    if (n < 2) return fail(OSLAM_E_INVALID, "model needs at least 2 points");
+    if (n > 46340) return fail(OSLAM_E_LIMIT, "model larger than 46340 points (32-bit pair index, kernel.cu:433)");
+    m = (oslam_model *)calloc(1, sizeof *m);
+    if (!m) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    if (params) m->params = *params; else oslam_params_default(&m->params);
+    if (m->params.max_cells == 0) m->params.max_cells = 1u << 22;
+    rc = pick_device(m->params.dev, &m->dev);
+    if (rc != OSLAM_OK) goto done;
+    rc = cloud_upload(&m->c, xyz, nrm, n, stride_bytes);
+    if (rc != OSLAM_OK) goto done;
+    m->d_dist = d_dist;
+    m->inv_d_dist = 1.0f / d_dist;
+    m->weights = (float *)malloc(sizeof(float) * n);
+    if (!m->weights) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    for (s = 0; s < (int)n; s++) m->weights[s] = 1.0f;          /* model.cu:67 */
+
+    n_slices = (int)((n + OSLAMK_SLICE - 1) / OSLAMK_SLICE);
+    if (n_slices > 64) { rc = fail(OSLAM_E_LIMIT, "too many model slices"); goto done; }
+    HIPCHK(hipMalloc((void **)&d_small, sizeof(uint32_t) * (64 + 3)));
+
+    /* pass 1 with table growth: a slice table is kept at most half full */
+    for (cap = 1u << 16;; cap <<= 1) {
+        int grow = 0;
+        uint32_t lg = 0;
+        while ((1u << lg) < cap) lg++;
+        if (m->table.slots) { (void)hipFree(m->table.slots); m->table.slots = NULL; }
+        HIPCHK(hipMalloc((void **)&m->table.slots, sizeof(oslamk_slot) * (size_t)cap * n_slices));
+        HIPCHK(hipMemsetAsync(m->table.slots, 0, sizeof(oslamk_slot) * (size_t)cap * n_slices, (hipStream_t)g_stream));
+        HIPCHK(hipMemsetAsync(d_small, 0, sizeof(uint32_t) * (64 + 3), (hipStream_t)g_stream));
+        m->table.cap = cap;
+        m->table.shift = 32 - lg;
+        m->table.n_slices = n_slices;
+        KCHK(oslamk_model_count(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_small, d_small + 64, g_stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+        HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
+        if (h_small[64]) grow = 1;
+        for (s = 0; s < n_slices; s++) if (h_small[s] > cap / 2) grow = 1;
+        if (!grow) break;
+        if (cap >= (1u << 26)) { rc = fail(OSLAM_E_LIMIT, "model hash table would exceed 2^26 slots per slice"); goto done; }
+    }
+    KCHK(oslamk_table_scan(m->table, d_small + 65, g_stream));
+    KCHK(oslamk_table_mark_first(m->table, d_small + 66, g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
+    m->n_entries = h_small[65];
+    m->num_model_keys = (uint64_t)h_small[66] + 1;    /* + the key-0 bucket of the n self pairs */
+    n_pairs = m->n_entries ? m->n_entries : 1;
+
+    /* rows y,z of T_m_g per model point, on the host with libm (kernel.cu:310-318) */
+    h_tmg = (float *)malloc(sizeof(float) * 8 * n);
+    if (!h_tmg) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    oslam_T_g_rows(m->c.h_xyz, m->c.h_nrm, NULL, n, h_tmg);
+    HIPCHK(hipMalloc((void **)&d_tmg, sizeof(float) * 8 * n));
+    HIPCHK(hipMemcpy(d_tmg, h_tmg, sizeof(float) * 8 * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&m->exact, sizeof(oslamk_entry_exact) * n_pairs));
+    if (m->params.vote_mode == OSLAM_VOTE_FAST)
+        HIPCHK(hipMalloc((void **)&m->fast, sizeof(oslamk_entry_fast) * n_pairs));
+    KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->exact, m->fast, g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+
+    m->out_cap = m->params.max_cells;
+    HIPCHK(hipMalloc((void **)&m->d_counters, sizeof(oslamk_counters)));
+    HIPCHK(hipMalloc((void **)&m->d_out, sizeof(oslamk_cell) * (size_t)m->out_cap));
+    m->h_out = (oslam_cell *)malloc(sizeof(oslam_cell) * (size_t)m->out_cap);
+    if (!m->h_out) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+done:
+    free(h_tmg);
+    if (d_tmg) (void)hipFree(d_tmg);
+    if (d_small) (void)hipFree(d_small);
+    if (rc != OSLAM_OK) { oslam_model_destroy(m); return rc; }
+    *out = m;
+    return OSLAM_OK;
+}
+
+int oslam_model_set_point_weights(oslam_model *m, const float *weights, size_t n)
+{
+    if (!m || !weights || n != (size_t)m->c.n) return fail(OSLAM_E_INVALID, "bad weights");
+    memcpy(m->weights, weights, sizeof(float) * n);
+    return OSLAM_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+void oslam_scene_destroy(oslam_scene *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->dev);
+    cloud_free(&s->c);
+    free(s->h_ref_idx);
+    if (s->d_ref_idx) (void)hipFree(s->d_ref_idx);
+    if (s->d_tsg) (void)hipFree(s->d_tsg);
+    free(s);
+}
+
+int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
+                       float d_dist, unsigned df, const oslam_params *params, oslam_scene **out)
+{
+    int rc = OSLAM_OK;
+    oslam_scene *s = NULL;
+    oslam_params p;
+    float *h_tsg = NULL;
+    size_t n_all, t;
+
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (!xyz || !nrm || stride_bytes < 12 || !(d_dist > 0.0f) || df == 0) return fail(OSLAM_E_INVALID, "bad scene arguments");
+    if (n < 2) return fail(OSLAM_E_INVALID, "scene needs at least 2 points");
+    if (n > 0x7fffffffu) return fail(OSLAM_E_LIMIT, "scene too large");
+    if (params) p = *params; else oslam_params_default(&p);
+    if (p.shard_world < 1 || p.shard_rank < 0 || p.shard_rank >= p.shard_world) return fail(OSLAM_E_INVALID, "bad shard");
+    s = (oslam_scene *)calloc(1, sizeof *s);
+    if (!s) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    rc = pick_device(p.dev, &s->dev);
+    if (rc != OSLAM_OK) goto done;
+    rc = cloud_upload(&s->c, xyz, nrm, n, stride_bytes);
+    if (rc != OSLAM_OK) goto done;
+    s->d_dist = d_dist;
+    s->df = df;
+    s->rank = p.shard_rank;
+    s->world = p.shard_world;
+    /* reference points: idx % df == 0 (kernel.cu:432), dealt round-robin to ranks */
+    n_all = (n + df - 1) / df;
+    s->n_ref = 0;
+    for (t = (size_t)s->rank; t < n_all; t += (size_t)s->world) s->n_ref++;
+    s->h_ref_idx = (uint32_t *)malloc(sizeof(uint32_t) * (s->n_ref ? s->n_ref : 1));
+    h_tsg = (float *)malloc(sizeof(float) * 8 * (s->n_ref ? s->n_ref : 1));
+    if (!s->h_ref_idx || !h_tsg) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    {
+        int k = 0;
+        for (t = (size_t)s->rank; t < n_all; t += (size_t)s->world) s->h_ref_idx[k++] = (uint32_t)(t * df);
+    }
+    oslam_T_g_rows(s->c.h_xyz, s->c.h_nrm, s->h_ref_idx, (size_t)s->n_ref, h_tsg);
+    HIPCHK(hipMalloc((void **)&s->d_ref_idx, sizeof(uint32_t) * (s->n_ref ? s->n_ref : 1)));
+    HIPCHK(hipMalloc((void **)&s->d_tsg, sizeof(float) * 8 * (s->n_ref ? s->n_ref : 1)));
+    if (s->n_ref) {
+        HIPCHK(hipMemcpy(s->d_ref_idx, s->h_ref_idx, sizeof(uint32_t) * s->n_ref, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->d_tsg, h_tsg, sizeof(float) * 8 * s->n_ref, hipMemcpyHostToDevice));
+    }
+done:
+    free(h_tsg);
+    if (rc != OSLAM_OK) { oslam_scene_destroy(s); return rc; }
+    *out = s;
+    return OSLAM_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+static int check_pair(const oslam_model *m, const oslam_scene *s)
+{
+    if (!m || !s) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (m->dev != s->dev) return fail(OSLAM_E_INVALID, "model and scene live on different devices");
+    if (m->d_dist != s->d_dist) return fail(OSLAM_E_INVALID, "scene d_dist differs from the model's (ppf.cu:64-67)");
+    return OSLAM_OK;
+}
+
+/* run the vote kernel over the scene's shard; leaves emitted cells in m->h_out */
+static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
+                     float *ms_out, uint32_t *launches)
+{
+    int rc = OSLAM_OK;
+    hipEvent_t e0 = NULL, e1 = NULL;
+    oslamk_vote_args a;
+    hipStream_t st = (hipStream_t)g_stream;
+    memset(&a, 0, sizeof a);
+    a.scene = s->c.k;
+    a.ref_idx = s->d_ref_idx;
+    a.tsg = s->d_tsg;
+    a.n_ref = s->n_ref;
+    a.d_dist = m->d_dist;
+    a.inv_d_dist = m->inv_d_dist;
+    a.table = m->table;
+    a.exact = m->exact;
+    a.fast = m->fast;
+    a.thresh = m->params.vote_count_threshold;
+    a.fixed_gmax = fixed_gmax;
+    a.counters = m->d_counters;
+    a.out = m->d_out;
+    a.out_cap = m->out_cap;
+    a.acc_dump = NULL;
+    a.dump_ref = -1;
+    a.first_ref = 0;
+    a.n_launch = s->n_ref;
+    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST && m->fast) ? 1 : 0;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
+    HIPCHK(hipEventRecord(e0, st));
+    KCHK(oslamk_vote(&a, g_stream));
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipMemcpyAsync(cnt, m->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, e0, e1));
+    if (launches) *launches += 1;
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+/* vote + D2H of emitted cells; handles an overflowing record buffer by a second,
+ * exactly thresholded launch */
+static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, size_t *n_cells,
+                          oslam_stats *st)
+{
+    int rc = OSLAM_OK;
+    float ms = 0.0f, ms2 = 0.0f;
+    uint32_t launches = 0;
+    rc = run_votes(m, s, 0, cnt, &ms, &launches);
+    if (rc != OSLAM_OK) return rc;
+    if (cnt->out_count > m->out_cap) {
+        uint32_t g = cnt->gmax;
+        rc = run_votes(m, s, g, cnt, &ms2, &launches);
+        if (rc != OSLAM_OK) return rc;
+        cnt->gmax = g;
+        if (cnt->out_count > m->out_cap)
+            return fail(OSLAM_E_LIMIT, "more accumulator peaks than params.max_cells");
+    }
+    *n_cells = cnt->out_count;
+    if (*n_cells) {
+        HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * *n_cells, hipMemcpyDeviceToHost));
+    }
+    if (st) {
+        st->num_scene_ppfs = (uint64_t)s->n_ref * (uint64_t)(s->c.n - 1);
+        st->num_hits = cnt->hits;
+        st->num_votes = cnt->votes;
+        st->num_unique_votes = cnt->nonzero_cells;
+        st->num_model_keys = m->num_model_keys;
+        st->max_count = cnt->gmax;
+        st->num_emitted = cnt->out_count;
+        st->ms_vote = ms + ms2;
+        st->vote_launches = launches;
+    }
+done:
+    return rc;
+}
+
+static int finish_cells(oslam_model *m, oslam_scene *s, oslam_cell *cells, size_t n, uint32_t gmax,
+                        float T[16], oslam_stats *st)
+{
+    int rc;
+    n = oslam_filter_cells(cells, n, m->params.vote_count_threshold, gmax);
+    oslam_sort_cells(cells, n);
+    free(m->last_cells);
+    free(m->last_poses);
+    m->last_cells = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
+    m->last_poses = (float *)calloc(16 * (n ? n : 1), sizeof(float));
+    m->n_last = 0;
+    if (!m->last_cells || !m->last_poses) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    memcpy(m->last_cells, cells, sizeof(oslam_cell) * n);
+    m->n_last = n;
+    if (st) { st->num_top = n; st->max_count = gmax; }
+    rc = oslam_pose_stage(cells, n, m->c.h_xyz, m->c.h_nrm, (size_t)m->c.n, s->c.h_xyz, s->c.h_nrm,
+                          (size_t)s->c.n, m->d_dist, m->params.cpu_clustering, m->params.use_l1_norm,
+                          m->params.use_averaged_clusters, m->weights, T, m->last_poses);
+    if (rc == OSLAM_E_NO_VOTES) return fail(rc, "no scene pair matched the model");
+    if (rc != OSLAM_OK) return fail(rc, "pose stage failed");
+    return OSLAM_OK;
+}
+
+int oslam_align(oslam_model *m, oslam_scene *s, float T[16], oslam_stats *stats)
+{
+    int rc;
+    oslamk_counters cnt;
+    size_t n = 0;
+    oslam_stats local;
+    double t0 = now_ms();
+    if (!T) return fail(OSLAM_E_INVALID, "T is NULL");
+    memset(T, 0, 16 * sizeof(float));
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (!stats) stats = &local;
+    memset(stats, 0, sizeof *stats);
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    rc = vote_and_fetch(m, s, &cnt, &n, stats);
+    if (rc != OSLAM_OK) return rc;
+    rc = finish_cells(m, s, m->h_out, n, cnt.gmax, T, stats);
+    stats->ms_total = (float)(now_ms() - t0);
+    return rc;
+}
+
+int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, size_t cap,
+                      size_t *n_out, uint32_t *local_max_out, oslam_stats *stats)
+{
+    int rc;
+    oslamk_counters cnt;
+    size_t n = 0;
+    oslam_stats local;
+    double t0 = now_ms();
+    if (!cells_out || !n_out || !local_max_out) return fail(OSLAM_E_INVALID, "NULL output");
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (!stats) stats = &local;
+    memset(stats, 0, sizeof *stats);
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    rc = vote_and_fetch(m, s, &cnt, &n, stats);
+    if (rc != OSLAM_OK) return rc;
+    /* peaks above the local threshold: a superset of what survives the global one */
+    n = oslam_filter_cells(m->h_out, n, m->params.vote_count_threshold, cnt.gmax);
+    oslam_sort_cells(m->h_out, n);
+    if (n > cap) n = cap;     /* the strongest peaks are kept; cap is sized by the caller */
+    memcpy(cells_out, m->h_out, sizeof(oslam_cell) * n);
+    *n_out = n;
+    *local_max_out = cnt.gmax;
+    stats->ms_total = (float)(now_ms() - t0);
+    return OSLAM_OK;
+}
+
+int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, size_t n,
+                       uint32_t global_max, float T[16], oslam_stats *stats)
+{
+    int rc;
+    oslam_cell *tmp;
+    oslam_stats local;
+    if (!T || (!cells && n)) return fail(OSLAM_E_INVALID, "NULL argument");
+    memset(T, 0, 16 * sizeof(float));
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (!stats) stats = &local;
+    tmp = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
+    if (!tmp) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    memcpy(tmp, cells, sizeof(oslam_cell) * n);
+    rc = finish_cells(m, s, tmp, n, global_max, T, stats);
+    free(tmp);
+    return rc;
+}
+
+int oslam_ppf_registration(const float *const *scene_xyz, const float *const *scene_nrm,
+                           const size_t *scene_n, size_t n_scenes, const float *const *model_xyz,
+                           const float *const *model_nrm, const size_t *model_n, size_t n_models,
+                           size_t stride_bytes, const float *model_d_dists, unsigned df,
+                           float vote_count_threshold, int cpu_clustering, int use_l1_norm,
+                           int use_averaged_clusters, int devUse, const float *model_weights,
+                           float *T_out)
+{
+    oslam_params p;
+    oslam_model **models = NULL;
+    size_t i, j;
+    int rc = OSLAM_OK;
+    (void)model_weights;                       /* ignored by the reference too: ppf.cu:35 */
+    if (!scene_xyz || !scene_nrm || !scene_n || !model_xyz || !model_nrm || !model_n || !model_d_dists || !T_out)
+        return fail(OSLAM_E_INVALID, "NULL argument");
+    oslam_params_default(&p);
+    p.ref_point_df = df;
+    p.vote_count_threshold = vote_count_threshold;
+    p.cpu_clustering = cpu_clustering;
+    p.use_l1_norm = use_l1_norm;
+    p.use_averaged_clusters = use_averaged_clusters;
+    p.dev = devUse;
+    memset(T_out, 0, sizeof(float) * 16 * n_scenes * n_models);
+    models = (oslam_model **)calloc(n_models ? n_models : 1, sizeof *models);
+    if (!models) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    /* models are built once and stay resident (the reference rebuilds per pair) */
+    for (j = 0; j < n_models && rc == OSLAM_OK; j++)
+        rc = oslam_model_create(model_xyz[j], model_nrm[j], model_n[j], stride_bytes, model_d_dists[j], &p, &models[j]);
+    for (i = 0; i < n_scenes && rc == OSLAM_OK; i++) {
+        for (j = 0; j < n_models && rc == OSLAM_OK; j++) {
+            oslam_scene *sc = NULL;
+            /* the scene is prepared per model: its keys depend on the model's d_dist (ppf.cu:64-67) */
+            rc = oslam_scene_create(scene_xyz[i], scene_nrm[i], scene_n[i], stride_bytes, model_d_dists[j], df, &p, &sc);
+            if (rc == OSLAM_OK) {
+                int arc = oslam_align(models[j], sc, T_out + 16 * (i * n_models + j), NULL);
+                if (arc != OSLAM_OK && arc != OSLAM_E_NO_VOTES) rc = arc;
+            }
+            oslam_scene_destroy(sc);
+        }
+    }
+    for (j = 0; j < n_models; j++) oslam_model_destroy(models[j]);
+    free(models);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* parity taps */
+static int cloud_row_keys(cloud_buf *c, size_t ref, float d_dist, uint32_t *keys_out)
+{
+    int rc = OSLAM_OK;
+    uint32_t *d = NULL;
+    if (!keys_out || ref >= (size_t)c->n) return fail(OSLAM_E_INVALID, "bad reference index");
+    HIPCHK(hipMalloc((void **)&d, sizeof(uint32_t) * c->n));
+    KCHK(oslamk_row_keys(c->k, (int)ref, d_dist, 1.0f / d_dist, d, g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    HIPCHK(hipMemcpy(keys_out, d, sizeof(uint32_t) * c->n, hipMemcpyDeviceToHost));
+done:
+    if (d) (void)hipFree(d);
+    return rc;
+}
+
+int oslam_scene_keys(oslam_scene *s, size_t ref_index, uint32_t *keys_out)
+{
+    if (!s) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (hipSetDevice(s->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    return cloud_row_keys(&s->c, ref_index, s->d_dist, keys_out);
+}
+
+int oslam_model_keys(oslam_model *m, size_t ref_index, uint32_t *keys_out)
+{
+    if (!m) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    return cloud_row_keys(&m->c, ref_index, m->d_dist, keys_out);
+}
+
+static int u32_order(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : (x > y);
+}
+
+int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t cap, size_t *count_out)
+{
+    int rc = OSLAM_OK;
+    size_t total = 0, written = 0, n_slots;
+    int s;
+    oslamk_entry_exact *tmp = NULL;
+    if (!m || !count_out) return fail(OSLAM_E_INVALID, "NULL argument");
+    *count_out = 0;
+    if (key == 0) return OSLAM_OK;             /* never matched: kernel.cu:491 */
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    n_slots = (size_t)m->table.cap * m->table.n_slices;
+    if (!m->h_slots) {
+        m->h_slots = (oslamk_slot *)malloc(sizeof(oslamk_slot) * n_slots);
+        if (!m->h_slots) return fail(OSLAM_E_NOMEM, "host allocation failed");
+        HIPCHK(hipMemcpy(m->h_slots, m->table.slots, sizeof(oslamk_slot) * n_slots, hipMemcpyDeviceToHost));
+    }
+    for (s = 0; s < m->table.n_slices; s++) {
+        const oslamk_slot *tab = m->h_slots + (size_t)s * m->table.cap;
+        uint32_t mask = m->table.cap - 1, slot = (key * 2654435761u) >> m->table.shift, probe;
+        for (probe = 0; probe <= mask; probe++) {
+            if (tab[slot].key == key) {
+                uint32_t len = tab[slot].len & 0x7fffffffu, e;
+                tmp = (oslamk_entry_exact *)realloc(tmp, sizeof(oslamk_entry_exact) * (len ? len : 1));
+                HIPCHK(hipMemcpy(tmp, m->exact + tab[slot].start, sizeof(oslamk_entry_exact) * len, hipMemcpyDeviceToHost));
+                for (e = 0; e < len; e++, total++)
+                    if (pairs_out && written < cap) pairs_out[written++] = tmp[e].m_r * (uint32_t)m->c.n + tmp[e].m_i;
+                break;
+            }
+            if (tab[slot].key == 0) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+    if (pairs_out) qsort(pairs_out, written, sizeof(uint32_t), u32_order);
+    *count_out = total;
+done:
+    free(tmp);
+    return rc;
+}
+
+int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uint32_t *acc_out)
+{
+    int rc = OSLAM_OK;
+    uint32_t *d_dump = NULL, *d_ref = NULL, *h_dump = NULL;
+    float *d_tsg = NULL;
+    float rows[8];
+    uint32_t ref = (uint32_t)ref_index;
+    oslamk_vote_args a;
+    size_t cells;
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (!acc_out || ref_index >= (size_t)s->c.n) return fail(OSLAM_E_INVALID, "bad reference index");
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    cells = (size_t)m->table.n_slices * OSLAMK_SLICE * OSLAMK_NBIN;
+    oslam_T_g_rows(s->c.h_xyz, s->c.h_nrm, &ref, 1, rows);
+    HIPCHK(hipMalloc((void **)&d_dump, sizeof(uint32_t) * cells));
+    HIPCHK(hipMalloc((void **)&d_ref, sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&d_tsg, sizeof rows));
+    HIPCHK(hipMemcpy(d_ref, &ref, sizeof ref, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tsg, rows, sizeof rows, hipMemcpyHostToDevice));
+    memset(&a, 0, sizeof a);
+    a.scene = s->c.k;
+    a.ref_idx = d_ref;
+    a.tsg = d_tsg;
+    a.n_ref = 1;
+    a.d_dist = m->d_dist;
+    a.inv_d_dist = m->inv_d_dist;
+    a.table = m->table;
+    a.exact = m->exact;
+    a.fast = m->fast;
+    a.thresh = m->params.vote_count_threshold;
+    a.fixed_gmax = 0xffffffffu;                /* emit nothing */
+    a.counters = m->d_counters;
+    a.out = m->d_out;
+    a.out_cap = m->out_cap;
+    a.acc_dump = d_dump;
+    a.dump_ref = 0;
+    a.first_ref = 0;
+    a.n_launch = 1;
+    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST && m->fast) ? 1 : 0;
+    HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), (hipStream_t)g_stream));
+    KCHK(oslamk_vote(&a, g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    h_dump = (uint32_t *)malloc(sizeof(uint32_t) * cells);
+    if (!h_dump) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    HIPCHK(hipMemcpy(h_dump, d_dump, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
+    memcpy(acc_out, h_dump, sizeof(uint32_t) * OSLAMK_NBIN * (size_t)m->c.n);
+done:
+    free(h_dump);
+    if (d_dump) (void)hipFree(d_dump);
+    if (d_ref) (void)hipFree(d_ref);
+    if (d_tsg) (void)hipFree(d_tsg);
+    return rc;
+}
+
+int oslam_last_cells(oslam_model *m, oslam_cell *cells_out, float *poses_out, size_t cap, size_t *n_out)
+{
+    size_t n;
+    if (!m || !n_out) return fail(OSLAM_E_INVALID, "NULL argument");
+    n = m->n_last < cap ? m->n_last : cap;
+    if (cells_out) memcpy(cells_out, m->last_cells, sizeof(oslam_cell) * n);
+    if (poses_out) memcpy(poses_out, m->last_poses, sizeof(float) * 16 * n);
+    *n_out = m->n_last;
+    return OSLAM_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+static uint64_t sm64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+int oslam_selftest_math(size_t n, uint64_t seed, uint64_t *mismatches)
+{
+    int rc = OSLAM_OK, dev;
+    float *h = NULL, *d = NULL, *ho = NULL;
+    size_t i;
+    uint64_t bad = 0;
+    if (!mismatches || n == 0) return fail(OSLAM_E_INVALID, "bad arguments");
+    rc = pick_device(0, &dev);
+    if (rc != OSLAM_OK) return rc;
+    h = (float *)malloc(sizeof(float) * 3 * n);
+    ho = (float *)malloc(sizeof(float) * 4 * n);
+    if (!h || !ho) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    for (i = 0; i < n; i++) {
+        uint64_t r = sm64(&seed), r2 = sm64(&seed);
+        float x, y, x2;
+        switch (i & 3) {
+        case 0:   /* acos domain, dense near +-1 and +-0.5 */
+            x = (float)((double)(int32_t)(uint32_t)r / 2147483648.0);
+            y = (float)((double)(int32_t)(uint32_t)(r >> 32) / 2147483648.0 * 3.0);
+            x2 = (float)((double)(int32_t)(uint32_t)r2 / 2147483648.0 * 3.0);
+            break;
+        case 1:
+            x = 1.0f - (float)((double)(uint32_t)r / 4294967296.0) * 1e-3f;
+            if (r2 & 1) x = -x;
+            y = (float)((double)(int32_t)(uint32_t)(r >> 32) / 2147483648.0);
+            x2 = y * ((r2 & 2) ? 0.4375f : 2.4375f) * (1.0f + (float)(int)((r2 >> 8) & 15) * 1e-7f);
+            break;
+        case 2:   /* raw bit patterns */
+            x = PM_BITS_U2F((uint32_t)r);
+            y = PM_BITS_U2F((uint32_t)(r >> 32));
+            x2 = PM_BITS_U2F((uint32_t)r2);
+            break;
+        default:
+            x = (float)((double)(int32_t)(uint32_t)r / 2147483648.0 * 1.00001);
+            y = (float)((double)(int32_t)(uint32_t)(r >> 32) / 2147483648.0 * 1e-3);
+            x2 = (float)((double)(int32_t)(uint32_t)r2 / 2147483648.0 * 1e3);
+            break;
+        }
+        h[i] = x; h[n + i] = y; h[2 * n + i] = x2;
+    }
+    HIPCHK(hipMalloc((void **)&d, sizeof(float) * 7 * n));
+    HIPCHK(hipMemcpy(d, h, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    KCHK(oslamk_selftest(d, d + n, d + 2 * n, n, d + 3 * n, d + 4 * n, (uint32_t *)(d + 5 * n),
+                         (uint32_t *)(d + 6 * n), g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    HIPCHK(hipMemcpy(ho, d + 3 * n, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+    for (i = 0; i < n; i++) {
+        float x = h[i], y = h[n + i], x2 = h[2 * n + i];
+        float a = pm_acosf(x), t = pm_atan2f(y, x2);
+        float st = 0.0371f + pm_fabsf(x) * 0.01f;
+        uint32_t q = pc_quant_bits(pm_fabsf(y) * 7.0f, st, 1.0f / st);
+        uint32_t b = pc_alpha_bin_exact(y, x2, x, y - x2);
+        uint32_t ga = PM_BITS_F2U(ho[i]), gt = PM_BITS_F2U(ho[n + i]);
+        int a_ok = pm_isnan(a) ? pm_isnan(ho[i]) : (PM_BITS_F2U(a) == ga);
+        int t_ok = pm_isnan(t) ? pm_isnan(ho[n + i]) : (PM_BITS_F2U(t) == gt);
+        if (!a_ok || !t_ok || q != ((uint32_t *)ho)[2 * n + i] || b != ((uint32_t *)ho)[3 * n + i]) bad++;
+    }
+    *mismatches = bad;
+done:
+    free(h);
+    free(ho);
+    if (d) (void)hipFree(d);
+    return rc;
+}

@@ -1,0 +1,118 @@
+/*
+ * oslam_kernels.h -- C launch interface of the gfx950 kernels
+ * (oslam_kernels.hip).  Internal to liboslam_hip.so; the public boundary is
+ * include/oslam.h.  All pointers are device pointers unless noted; `stream` is
+ * a hipStream_t passed as void*.  Launchers return a hipError_t as int.
+ */
+#ifndef OSLAM_KERNELS_H
+#define OSLAM_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSLAMK_SLICE 1024      /* model reference points per table slice / LDS accumulator */
+#define OSLAMK_NBIN 32         /* alpha bins per accumulator row (reference uses 0..30) */
+
+/* One slot of a slice's open-addressing table, keyed by the 32-bit PPF key. */
+typedef struct oslamk_slot {
+    uint32_t key;              /* 0 = empty (key 0 is never stored: kernel.cu:491) */
+    uint32_t start;            /* first entry of the bucket in the entry arrays */
+    uint32_t len;              /* bucket length; bit 31: no lower slice holds this key */
+    uint32_t cur;              /* fill cursor (== len after the build) */
+} oslamk_slot;
+
+/* Model pair entry, exact mode: what one vote needs of the model side. */
+typedef struct oslamk_entry_exact {
+    uint32_t m_r;
+    float uy, uz;              /* (T_m_g * m_i).y/.z, kernel.cu:330-332 */
+    uint32_t m_i;
+} oslamk_entry_exact;
+
+/* Model pair entry, fast mode: 8 bytes. */
+typedef struct oslamk_entry_fast {
+    uint32_t m_r;
+    float am;                  /* (alpha_m + pi) / D_ANGLE0 */
+} oslamk_entry_fast;
+
+/* A cloud in HBM: structure of arrays. */
+typedef struct oslamk_cloud {
+    const float *px, *py, *pz, *nx, *ny, *nz;
+    int n;
+} oslamk_cloud;
+
+typedef struct oslamk_table {
+    oslamk_slot *slots;        /* [n_slices][cap] */
+    uint32_t cap;              /* power of two */
+    uint32_t shift;            /* 32 - log2(cap) */
+    int n_slices;
+} oslamk_table;
+
+/* Counters one vote launch accumulates (device memory, zeroed by the host). */
+typedef struct oslamk_counters {
+    unsigned long long hits;
+    unsigned long long votes;
+    unsigned long long nonzero_cells;
+    uint32_t gmax;
+    uint32_t out_count;
+    uint32_t pad[2];
+} oslamk_counters;
+
+typedef struct oslamk_cell {
+    unsigned long long code;
+    uint32_t count;
+    uint32_t pad;
+} oslamk_cell;
+
+int oslamk_row_keys(oslamk_cloud c, int ref, float d_dist, float inv_d_dist, uint32_t *keys_out,
+                    void *stream);
+
+/* model build, pass 1: count pairs per (slice, key); n_unique[n_slices]; *overflow set if a
+ * slice table filled up */
+int oslamk_model_count(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
+                       uint32_t *n_unique, uint32_t *overflow, void *stream);
+/* exclusive scan of slot.len over all slots -> slot.start; total written to *total_out */
+int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
+/* mark slots whose key is in no lower slice (bit 31 of len); counts them in *n_first */
+int oslamk_table_mark_first(oslamk_table t, uint32_t *n_first, void *stream);
+/* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed).
+ * fast may be NULL. */
+int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
+                      const float *tmg, oslamk_entry_exact *exact, oslamk_entry_fast *fast,
+                      void *stream);
+
+typedef struct oslamk_vote_args {
+    oslamk_cloud scene;
+    const uint32_t *ref_idx;   /* [n_ref] scene indices of this shard's reference points */
+    const float *tsg;          /* [n_ref][8] rows y,z of T_s_g per reference point */
+    int n_ref;
+    float d_dist, inv_d_dist;
+    oslamk_table table;
+    const oslamk_entry_exact *exact;
+    const oslamk_entry_fast *fast;
+    float thresh;              /* vote_count_threshold */
+    uint32_t fixed_gmax;       /* != 0: emit cells with count > thresh*fixed_gmax only */
+    oslamk_counters *counters;
+    oslamk_cell *out;          /* [out_cap] */
+    uint32_t out_cap;
+    uint32_t *acc_dump;        /* optional [n_slices*SLICE][NBIN] for reference ordinal dump_ref */
+    int dump_ref;
+    int first_ref;             /* launch covers reference ordinals first_ref .. first_ref+n_launch-1 */
+    int n_launch;
+    int mode;                  /* 0 exact, 1 fast */
+} oslamk_vote_args;
+
+int oslamk_vote(const oslamk_vote_args *a, void *stream);
+
+/* device self-test: out_acos[i] = pm_acosf(x[i]); out_atan2[i] = pm_atan2f(y[i], x2[i]);
+ * out_bin[i] = pc_alpha_bin_exact(...) */
+int oslamk_selftest(const float *x, const float *y, const float *x2, size_t n, float *out_acos,
+                    float *out_atan2, uint32_t *out_quant, uint32_t *out_bin, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

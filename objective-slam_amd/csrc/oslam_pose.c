@@ -1,0 +1,389 @@
+/*
+ * oslam_pose.c -- host stage of the PPF path (C, libm): accumulator peaks ->
+ * candidate poses -> clustering -> best pose.
+ *
+ * Reference counterparts (pcl/alignment/): trans_calc_kernel2 and helpers
+ * (src/cuda/kernel.cu:352-401,605-645), vote_weight_kernel (:766-782),
+ * mat2transquat_kernel (:124-144,647-661), trans2idx_kernel (:663-699),
+ * rot_clustering_kernel (:702-763), Model::ClusterTransformations and
+ * ppf_lookup (src/cuda/model.cu:202-306), clusterPoses
+ * (src/transformation_clustering.cpp:62-137), result extraction
+ * (src/cuda/ppf.cu:74-93), ht_dist (src/cuda/linalg.cu:9-20).
+ * The reference runs these as tiny GPU kernels over a few thousand poses; here
+ * they run on the host after the (multi-GPU) gather of peaks.  The float
+ * operation order of the reference is kept, so results do not depend on which
+ * side computes them.  Known reference quirks are reproduced, not fixed:
+ * kernels that return early for count <= 1 leave zero poses; the pose (0,0,0)
+ * code is skipped; a pose's own votes count as 1 in clustering; the centre
+ * cell is not searched; quaternions are normalised by |q|^(1/2).
+ */
+#include "oslam_pose.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ppf_math.h"
+
+#define POSE_PI PM_PI_F
+#define POSE_D PM_D_ANGLE
+
+/* ---- 4x4 row-major helpers with the reference's evaluation order ---- */
+static void mat_zero(float *T) { memset(T, 0, 16 * sizeof(float)); }
+
+static void mat_mul(const float *A, const float *B, float *C)   /* kernel.cu:211-223 */
+{
+    int i, j, k;
+    mat_zero(C);
+    for (i = 0; i < 4; i++)
+        for (j = 0; j < 4; j++)
+            for (k = 0; k < 4; k++) C[4 * i + j] += A[4 * i + k] * B[4 * k + j];
+}
+
+static float row_dot4(const float *row, float x, float y, float z, float w)   /* :55-57 */
+{
+    return row[0] * x + row[1] * y + row[2] * z + row[3] * w;
+}
+
+static void mat_translation(float x, float y, float z, float *T)   /* :170-179 */
+{
+    mat_zero(T);
+    T[0] = 1; T[5] = 1; T[10] = 1; T[15] = 1;
+    T[3] = x; T[7] = y; T[11] = z;
+}
+
+static void mat_rot(int axis, float theta, float *T)   /* rotx/roty/rotz :181-209 */
+{
+    float c = cosf(theta), s = sinf(theta), ms = -1 * s;
+    mat_zero(T);
+    T[15] = 1;
+    if (axis == 0) { T[0] = 1; T[5] = c; T[9] = s; T[6] = ms; T[10] = c; }
+    else if (axis == 1) { T[0] = c; T[2] = s; T[5] = 1; T[8] = ms; T[10] = c; }
+    else { T[0] = c; T[4] = s; T[1] = ms; T[5] = c; T[10] = 1; }
+}
+
+static void mat_inv_rigid(const float *T, float *I)   /* invht :254-299 */
+{
+    float nr[9];
+    int i, j;
+    for (i = 0; i < 3; i++)
+        for (j = 0; j < 3; j++) {
+            I[4 * i + j] = T[4 * j + i];
+            nr[3 * i + j] = -I[4 * i + j];
+        }
+    for (i = 0; i < 3; i++)
+        I[4 * i + 3] = nr[3 * i] * T[3] + nr[3 * i + 1] * T[7] + nr[3 * i + 2] * T[11];
+    I[12] = 0; I[13] = 0; I[14] = 0; I[15] = 1;
+}
+
+void oslam_build_T_g(const float p[3], const float n[3], float T[16])
+{
+    float tr[16], ry[16], rz[16], tmp[16];
+    float nx, ny;
+    mat_translation(-1 * p[0], -1 * p[1], -1 * p[2], tr);
+    mat_rot(1, atan2f(n[2], n[0]), ry);
+    nx = row_dot4(ry, n[0], n[1], n[2], 1);
+    ny = row_dot4(ry + 4, n[0], n[1], n[2], 1);
+    mat_rot(2, -1 * atan2f(ny, nx), rz);
+    mat_mul(rz, ry, tmp);
+    mat_mul(tmp, tr, T);
+}
+
+void oslam_T_g_rows(const float *xyz, const float *nrm, const uint32_t *idx, size_t n,
+                    float *rows_out)
+{
+    size_t i;
+    for (i = 0; i < n; i++) {
+        float T[16];
+        size_t r = idx ? idx[i] : i;
+        oslam_build_T_g(xyz + 3 * r, nrm + 3 * r, T);
+        memcpy(rows_out + 8 * i, T + 4, 8 * sizeof(float));
+    }
+}
+
+/* ---- cells ---- */
+static int cell_order(const void *a, const void *b)
+{
+    const oslam_cell *x = (const oslam_cell *)a, *y = (const oslam_cell *)b;
+    if (x->count != y->count) return x->count > y->count ? -1 : 1;
+    if (x->code != y->code) return x->code < y->code ? -1 : 1;
+    return 0;
+}
+
+void oslam_sort_cells(oslam_cell *cells, size_t n) { qsort(cells, n, sizeof(oslam_cell), cell_order); }
+
+size_t oslam_filter_cells(oslam_cell *cells, size_t n, float thresh, uint32_t gmax)
+{
+    float min_votecount = thresh * gmax;          /* model.cu:164 */
+    size_t i, k = 0;
+    for (i = 0; i < n; i++)
+        if (cells[i].count > min_votecount) cells[k++] = cells[i];
+    return k;
+}
+
+/* ---- K5: pose of one cell (kernel.cu:372-401) ---- */
+static void cell_pose(uint64_t code, const float *m_xyz, const float *m_nrm, const float *s_xyz,
+                      const float *s_nrm, float *T)
+{
+    uint32_t s = (uint32_t)(code >> 32), mac = (uint32_t)code;
+    uint32_t m = mac >> 6, a = mac & 63u;
+    float Tm[16], Ts[16], rx[16], inv[16], tmp[16];
+    oslam_build_T_g(m_xyz + 3 * (size_t)m, m_nrm + 3 * (size_t)m, Tm);
+    oslam_build_T_g(s_xyz + 3 * (size_t)s, s_nrm + 3 * (size_t)s, Ts);
+    mat_rot(0, a * POSE_D - POSE_PI, rx);
+    mat_inv_rigid(Ts, inv);
+    mat_mul(inv, rx, tmp);
+    mat_mul(tmp, Tm, T);
+}
+
+/* ---- K7 (kernel.cu:128-144): q = (w,x,y,z) ---- */
+static void pose_quat(const float *T, float q[4])
+{
+    float t = T[0] + T[5] + T[10];
+    float r = sqrtf(1 + t), n;
+    q[0] = 0.5f * r;
+    q[1] = copysignf(0.5f * sqrtf(1 + T[0] - T[5] - T[10]), T[9] - T[6]);
+    q[2] = copysignf(0.5f * sqrtf(1 - T[0] + T[5] - T[10]), T[2] - T[8]);
+    q[3] = copysignf(0.5f * sqrtf(1 - T[0] - T[5] + T[10]), T[4] - T[1]);
+    n = sqrtf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+/* ---- K8: translation cell and its FNV key (kernel.cu:663-699) ---- */
+static float quant_down(float x, float y) { return x - fmodf(x, y); }
+
+static uint32_t fnv_cell(const int32_t c[3])
+{
+    uint32_t h = PM_FNV_BASIS;
+    int i;
+    for (i = 0; i < 3; i++) h = pm_fnv1a_word(h, (uint32_t)c[i]);
+    return h;
+}
+
+typedef struct { uint32_t hash; uint32_t idx; } hash_idx;
+static int hash_idx_order(const void *a, const void *b)
+{
+    const hash_idx *x = (const hash_idx *)a, *y = (const hash_idx *)b;
+    if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+/* first position whose hash is >= h */
+static size_t hash_lower_bound(const hash_idx *v, size_t n, uint32_t h)
+{
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        if (v[mid].hash < h) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* ---- K6 + K8 + K9 + argmax: returns max_idx ---- */
+static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, const float *quat,
+                               float d_dist, int use_l1, int averaged, const float *weights)
+{
+    float *wv = (float *)malloc(sizeof(float) * n);
+    float *score = (float *)calloc(n, sizeof(float));
+    int32_t *cell = (int32_t *)malloc(sizeof(int32_t) * 3 * n);
+    hash_idx *hi = (hash_idx *)malloc(sizeof(hash_idx) * n);
+    const float rot_thresh = 2 * POSE_D, rot_thresh_sq = rot_thresh * rot_thresh;
+    size_t i, best = 0;
+    int dx, dy, dz;
+
+    for (i = 0; i < n; i++) {
+        uint32_t m = ((uint32_t)cells[i].code) >> 6;
+        float w = weights ? weights[m] : 1.0f;
+        int a;
+        wv[i] = w * cells[i].count;                          /* kernel.cu:777 */
+        for (a = 0; a < 3; a++) cell[3 * i + a] = (int32_t)(quant_down(trans[3 * i + a], d_dist) / d_dist);
+        hi[i].hash = fnv_cell(cell + 3 * i);
+        hi[i].idx = (uint32_t)i;
+    }
+    qsort(hi, n, sizeof(hash_idx), hash_idx_order);
+
+    for (i = 0; i < n; i++) {
+        const float *q = quat + 4 * i;
+        float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
+        float ox = tx, oy = ty, oz = tz;
+        float votes = 1;                                     /* kernel.cu:722 */
+        for (dx = -1; dx < 2; dx++)
+            for (dy = -1; dy < 2; dy++)
+                for (dz = -1; dz < 2; dz++) {
+                    int32_t nb[3];
+                    uint32_t h;
+                    size_t j;
+                    if (dx == 0 && dy == 0 && dz == 0) continue;   /* kernel.cu:684-689 */
+                    nb[0] = cell[3 * i] + dx; nb[1] = cell[3 * i + 1] + dy; nb[2] = cell[3 * i + 2] + dz;
+                    h = fnv_cell(nb);
+                    if (h == 0) continue;                          /* kernel.cu:727 */
+                    for (j = hash_lower_bound(hi, n, h); j < n && hi[j].hash == h; j++) {
+                        size_t o = hi[j].idx;
+                        const float *qo = quat + 4 * o;
+                        float oc = wv[o];
+                        float qd = fabsf(8 * (1 - (q[0] * qo[0] + q[1] * qo[1] + q[2] * qo[2] + q[3] * qo[3])));
+                        if (!(qd < rot_thresh_sq)) continue;
+                        if (!use_l1) {
+                            float ex = tx - trans[3 * o], ey = ty - trans[3 * o + 1], ez = tz - trans[3 * o + 2];
+                            if (!(sqrtf(ex * ex + ey * ey + ez * ez) < d_dist)) continue;
+                        }
+                        if (averaged) {                            /* kernel.cu:747-752 */
+                            float s;
+                            ox = votes * ox; oy = votes * oy; oz = votes * oz;
+                            ox = ox + wv[o] * trans[3 * o];
+                            oy = oy + wv[o] * trans[3 * o + 1];
+                            oz = oz + wv[o] * trans[3 * o + 2];
+                            s = 1 / (votes + oc);
+                            ox = s * ox; oy = s * oy; oz = s * oz;
+                        }
+                        votes += oc;
+                    }
+                }
+        score[i] = votes;
+        trans[3 * i] = ox; trans[3 * i + 1] = oy; trans[3 * i + 2] = oz;   /* kernel.cu:758 */
+    }
+    for (i = 1; i < n; i++) if (score[i] > score[best]) best = i;         /* model.cu:292-295 */
+    free(wv); free(score); free(cell); free(hi);
+    return best;
+}
+
+/* ---- Eigen-based pieces in closed form ---- */
+static void rot_to_quat_xyzw(const float *R9, float q[4])   /* Eigen::Quaternionf(Matrix3f) */
+{
+    float t = R9[0] + R9[4] + R9[8];
+    if (t > 0) {
+        t = sqrtf(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (R9[7] - R9[5]) * t;
+        q[1] = (R9[2] - R9[6]) * t;
+        q[2] = (R9[3] - R9[1]) * t;
+    } else {
+        int i = 0, j, k;
+        if (R9[4] > R9[0]) i = 1;
+        if (R9[8] > R9[4 * i]) i = 2;
+        j = (i + 1) % 3;
+        k = (j + 1) % 3;
+        t = sqrtf(R9[4 * i] - R9[4 * j] - R9[4 * k] + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (R9[3 * k + j] - R9[3 * j + k]) * t;
+        q[j] = (R9[3 * j + i] + R9[3 * i + j]) * t;
+        q[k] = (R9[3 * k + i] + R9[3 * i + k]) * t;
+    }
+}
+
+static float relative_angle(const float *A, const float *B)   /* |angle(Ra^-1 Rb)| */
+{
+    float R[9], q[4], s;
+    int i, j, k;
+    for (i = 0; i < 3; i++)
+        for (j = 0; j < 3; j++) {
+            s = 0;
+            for (k = 0; k < 3; k++) s += A[4 * k + i] * B[4 * k + j];
+            R[3 * i + j] = s;
+        }
+    rot_to_quat_xyzw(R, q);
+    return fabsf(2.0f * atan2f(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), fabsf(q[3])));
+}
+
+int oslam_ht_dist(const float A[16], const float B[16], float out[2])
+{
+    float dx, dy, dz;
+    if (!A || !B || !out) return OSLAM_E_INVALID;
+    dx = A[3] - B[3]; dy = A[7] - B[7]; dz = A[11] - B[11];
+    out[0] = sqrtf(dx * dx + dy * dy + dz * dz);
+    out[1] = relative_angle(A, B);
+    return OSLAM_OK;
+}
+
+/* greedy clustering, transformation_clustering.cpp:62-122; poses arrive sorted
+ * by votes; the first cluster's average pose is the result (ppf.cu:75-77) */
+static void cluster_greedy(const float *T, const oslam_cell *cells, size_t n, float trans_thresh,
+                           float rot_thresh, float *T_out)
+{
+    size_t *head = (size_t *)malloc(sizeof(size_t) * n);
+    size_t *member = (size_t *)malloc(sizeof(size_t) * n);
+    uint32_t *cvotes = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    size_t ncl = 0, p, c, win = 0, cnt = 0;
+    float ta[3] = {0, 0, 0}, qa[4] = {0, 0, 0, 0}, nq, x, y, z, w;
+    int i, j;
+    for (p = 0; p < n; p++) {
+        const float *P = T + 16 * p;
+        for (c = 0; c < ncl; c++) {
+            const float *H = T + 16 * head[c];
+            float ex = P[3] - H[3], ey = P[7] - H[7], ez = P[11] - H[11];
+            if (sqrtf(ex * ex + ey * ey + ez * ez) < trans_thresh && relative_angle(P, H) < rot_thresh) break;
+        }
+        if (c == ncl) { head[ncl] = p; cvotes[ncl] = 0; ncl++; }
+        member[p] = c;
+        cvotes[c] += cells[p].count;
+    }
+    for (c = 1; c < ncl; c++) if (cvotes[c] > cvotes[win]) win = c;   /* first of the sorted clusters */
+    for (p = 0; p < n; p++) {
+        float R[9], q[4];
+        if (member[p] != win) continue;
+        for (i = 0; i < 3; i++) for (j = 0; j < 3; j++) R[3 * i + j] = T[16 * p + 4 * i + j];
+        rot_to_quat_xyzw(R, q);
+        ta[0] += T[16 * p + 3]; ta[1] += T[16 * p + 7]; ta[2] += T[16 * p + 11];
+        for (i = 0; i < 4; i++) qa[i] += q[i];
+        cnt++;
+    }
+    for (i = 0; i < 3; i++) ta[i] /= (float)cnt;
+    for (i = 0; i < 4; i++) qa[i] /= (float)cnt;
+    nq = sqrtf(qa[0] * qa[0] + qa[1] * qa[1] + qa[2] * qa[2] + qa[3] * qa[3]);
+    x = qa[0] / nq; y = qa[1] / nq; z = qa[2] / nq; w = qa[3] / nq;
+    {
+        float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+        float twx = tx * w, twy = ty * w, twz = tz * w;
+        float txx = tx * x, txy = ty * x, txz = tz * x;
+        float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        T_out[0] = 1 - (tyy + tzz); T_out[1] = txy - twz; T_out[2] = txz + twy; T_out[3] = ta[0];
+        T_out[4] = txy + twz; T_out[5] = 1 - (txx + tzz); T_out[6] = tyz - twx; T_out[7] = ta[1];
+        T_out[8] = txz - twy; T_out[9] = tyz + twx; T_out[10] = 1 - (txx + tyy); T_out[11] = ta[2];
+        T_out[12] = 0; T_out[13] = 0; T_out[14] = 0; T_out[15] = 1;
+    }
+    free(head); free(member); free(cvotes);
+}
+
+int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, const float *m_nrm,
+                     size_t M, const float *s_xyz, const float *s_nrm, size_t S, float d_dist,
+                     int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
+                     const float *weights, float T_out[16], float *poses_out)
+{
+    float *poses;
+    size_t i;
+    memset(T_out, 0, 16 * sizeof(float));
+    if (n == 0) return OSLAM_E_NO_VOTES;
+    for (i = 0; i < n; i++) {
+        uint32_t s = (uint32_t)(cells[i].code >> 32), m = ((uint32_t)cells[i].code) >> 6;
+        if (s >= S || m >= M) return OSLAM_E_INVALID;
+    }
+    poses = (float *)calloc(16 * n, sizeof(float));
+    if (!poses) return OSLAM_E_NOMEM;
+    if (n > 1) {                                   /* kernel.cu:609: a single cell yields no pose */
+        for (i = 0; i < n; i++) {
+            if ((cells[i].code >> 32) == 0 && ((uint32_t)cells[i].code) == 0) continue;   /* :628-631 */
+            cell_pose(cells[i].code, m_xyz, m_nrm, s_xyz, s_nrm, poses + 16 * i);
+        }
+    }
+    if (cpu_clustering) {
+        cluster_greedy(poses, cells, n, d_dist, POSE_D, T_out);      /* model.cu:262-263 */
+    } else if (n > 1) {
+        float *trans = (float *)malloc(sizeof(float) * 3 * n);
+        float *quat = (float *)malloc(sizeof(float) * 4 * n);
+        size_t best;
+        for (i = 0; i < n; i++) {
+            trans[3 * i] = poses[16 * i + 3];
+            trans[3 * i + 1] = poses[16 * i + 7];
+            trans[3 * i + 2] = poses[16 * i + 11];
+            pose_quat(poses + 16 * i, quat + 4 * i);
+        }
+        best = cluster_by_cells(cells, n, trans, quat, d_dist, use_l1_norm, use_averaged_clusters, weights);
+        memcpy(T_out, poses + 16 * best, 16 * sizeof(float));
+        T_out[3] = trans[3 * best]; T_out[7] = trans[3 * best + 1]; T_out[11] = trans[3 * best + 2];
+        free(trans); free(quat);
+    }
+    if (poses_out) memcpy(poses_out, poses, 16 * n * sizeof(float));
+    free(poses);
+    return OSLAM_OK;
+}

@@ -1,0 +1,26 @@
+/*
+ * oslam_pose.h -- host-side tail of the path: accumulator peaks -> poses ->
+ * clustering -> best pose.  The north-star keeps this stage on the host, after
+ * the all-gather of per-GPU peaks; it touches a few thousand records.
+ * Internal to liboslam_hip.so (the exported wrappers are in include/oslam.h).
+ */
+#ifndef OSLAM_POSE_H
+#define OSLAM_POSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "oslam.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* rows y and z of T_g (8 floats) for n reference points: what the kernels need */
+void oslam_T_g_rows(const float *xyz, const float *nrm, const uint32_t *idx, size_t n,
+                    float *rows_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

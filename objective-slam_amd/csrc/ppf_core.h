@@ -1,0 +1,83 @@
+/*
+ * ppf_core.h -- the point-pair feature key and the alpha bin, written once for
+ * the host C code and the gfx950 kernels (product code; the CPU oracle has its
+ * own, independent restatement under oracle/).
+ *
+ * Follows the reference's arithmetic operation by operation
+ * (pcl/alignment/src/cuda/kernel.cu): compute_ppf :109-122, disc_feature
+ * :94-100, ppf_hash_kernel :460-477, hash :23-30, and the alpha part of
+ * trans_model_scene :338-342.
+ */
+#ifndef OSLAM_PPF_CORE_H
+#define OSLAM_PPF_CORE_H
+
+#include "ppf_math.h"
+
+#include <math.h>
+/* fmodf is exact by definition; libm on the host, the HIP device library on the GPU */
+#define PC_FMODF(x, y) fmodf((x), (y))
+
+/* x - fmodf(x, step) (kernel.cu:90-92) for x >= 0 or NaN; bits with the host's
+ * NaN pattern so that hashing the bytes matches an x86 build. */
+PM_HD uint32_t pc_quant_bits(float x, float step, float inv_step)
+{
+    int k;
+    float q = pm_quant_down_pos(x, step, inv_step, &k);
+    if (k < 0) q = x - PC_FMODF(x, step);      /* NaN, inf or an absurd quotient */
+    if (pm_isnan(q)) return PM_NAN_BITS;
+    return PM_BITS_F2U(q);
+}
+
+/* Key of the ordered pair (p1,n1) -> (p2,n2); 0 when the distance is not a
+ * finite number (the reference maps NaN in .x to key 0, kernel.cu:467-469).
+ * n1n = norm(n1) is passed in because the caller keeps it per point. */
+PM_HD uint32_t pc_pair_key(float p1x, float p1y, float p1z, float n1x, float n1y, float n1z,
+                           float n1n, float p2x, float p2y, float p2z, float n2x, float n2y,
+                           float n2z, float n2n, float d_dist, float inv_d_dist)
+{
+    const float D = PM_D_ANGLE;
+    const float invD = 1.0f / PM_D_ANGLE;
+    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    float nd = pm_sqrtf(dx * dx + dy * dy + dz * dz);
+    float a2 = pm_acosf((n1x * dx + n1y * dy + n1z * dz) / (n1n * nd));
+    float a3 = pm_acosf((n2x * dx + n2y * dy + n2z * dz) / (n2n * nd));
+    float a4 = pm_acosf((n1x * n2x + n1y * n2y + n1z * n2z) / (n1n * n2n));
+    int k;
+    float q1 = pm_quant_down_pos(nd, d_dist, inv_d_dist, &k);
+    uint32_t h;
+    if (k < 0) {
+        q1 = nd - PC_FMODF(nd, d_dist);
+        if (pm_isnan(q1)) return 0u;
+    }
+    h = pm_fnv1a_word(PM_FNV_BASIS, PM_BITS_F2U(q1));
+    h = pm_fnv1a_word(h, pc_quant_bits(a2, D, invD));
+    h = pm_fnv1a_word(h, pc_quant_bits(a3, D, invD));
+    h = pm_fnv1a_word(h, pc_quant_bits(a4, D, invD));
+    return h;
+}
+
+/* norm(n) as the reference computes it (kernel.cu:51-61) */
+PM_HD float pc_norm3(float x, float y, float z) { return pm_sqrtf(x * x + y * y + z * z); }
+
+/* y and z of T_g * (p, 1) with T_g rows given as 4 floats each
+ * (mat4f_vmul / dot(float4,float4), kernel.cu:55-57,234-242) */
+PM_HD float pc_row_dot(const float *row, float px, float py, float pz)
+{
+    return row[0] * px + row[1] * py + row[2] * pz + row[3] * 1.0f;
+}
+
+/* alpha bin of kernel.cu:338-342 from u = (0,uy,uz), v = (0,vy,vz):
+ * alpha = atan2f(cross(u,v).x, dot(u,v)); quant_downf(alpha + pi, D) / D.
+ * Returns 0..30, or 255 when alpha is NaN. */
+PM_HD unsigned pc_alpha_bin_exact(float uy, float uz, float vy, float vz)
+{
+    float cx = uy * vz - uz * vy;                 /* kernel.cu:84 */
+    float dt = 0.0f * 0.0f + uy * vy + uz * vz;   /* kernel.cu:52 with u.x = v.x = 0 */
+    float alpha = pm_atan2f(cx, dt) + PM_PI_F;
+    int k;
+    (void)pm_quant_down_pos(alpha, PM_D_ANGLE, 1.0f / PM_D_ANGLE, &k);
+    /* lrintf(RN(k*D)/D) == k for k <= 31: |RN(k*D)/D - k| <= 31*2^-23 */
+    return ((unsigned)k > 31u) ? 255u : (unsigned)k;
+}
+
+#endif /* OSLAM_PPF_CORE_H */

@@ -1,0 +1,341 @@
+"""Python mirror of the reference's registration interface over the C-ABI.
+
+The reference exposes (pcl/alignment/include/): ``ppf_registration(...)``
+(ppf.h:9-15), ``class Scene`` (scene.h:10-52) and ``class Model`` (model.h:14-115)
+with ``Model::ppf_lookup(Scene*)``.  The same names, argument meaning and result
+fields live here, on top of ``liboslam_hip.so`` (include/oslam.h) through ctypes.
+Clouds are numpy arrays: points ``[n,3]`` float32 and normals ``[n,3]`` float32,
+or one ``[n,12]`` float32 array laid out like ``pcl::PointNormal`` (48 bytes).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboslam_hip.so")
+_LIB = None
+
+OSLAM_OK, OSLAM_E_INVALID, OSLAM_E_DEVICE, OSLAM_E_NOMEM, OSLAM_E_NO_VOTES, OSLAM_E_LIMIT = range(6)
+VOTE_EXACT, VOTE_FAST = 0, 1
+
+
+class OslamError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("oslam error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("ref_point_df", C.c_uint), ("vote_count_threshold", C.c_float),
+                ("cpu_clustering", C.c_int), ("use_l1_norm", C.c_int), ("use_averaged_clusters", C.c_int),
+                ("dev", C.c_int), ("vote_mode", C.c_int), ("shard_rank", C.c_int), ("shard_world", C.c_int),
+                ("max_cells", C.c_uint), ("reserved", C.c_int * 6)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_scene_ppfs", C.c_uint64), ("num_hits", C.c_uint64), ("num_votes", C.c_uint64),
+                ("num_unique_votes", C.c_uint64), ("num_model_keys", C.c_uint64), ("num_top", C.c_uint64),
+                ("max_count", C.c_uint32), ("num_emitted", C.c_uint32), ("ms_vote", C.c_float),
+                ("ms_total", C.c_float), ("vote_launches", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+
+
+CELL_DTYPE = np.dtype([("code", "<u8"), ("count", "<u4"), ("pad", "<u4")])
+
+# every function include/oslam.h declares: (name, restype, argtypes)
+_vp, _sz, _f, _i, _u = C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_uint
+_SIGNATURES = {
+    "oslam_params_default": (_i, [C.POINTER(Params)]),
+    "oslam_d_dist_from_cloud": (_i, [_vp, _sz, _sz, _f, C.POINTER(_f)]),
+    "oslam_model_create": (_i, [_vp, _vp, _sz, _sz, _f, C.POINTER(Params), C.POINTER(_vp)]),
+    "oslam_model_destroy": (None, [_vp]),
+    "oslam_model_set_point_weights": (_i, [_vp, _vp, _sz]),
+    "oslam_scene_create": (_i, [_vp, _vp, _sz, _sz, _f, _u, C.POINTER(Params), C.POINTER(_vp)]),
+    "oslam_scene_destroy": (None, [_vp]),
+    "oslam_align": (_i, [_vp, _vp, _vp, C.POINTER(Stats)]),
+    "oslam_ppf_registration": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _u, _f, _i, _i, _i, _i, _vp, _vp]),
+    "oslam_ht_dist": (_i, [_vp, _vp, _vp]),
+    "oslam_build_T_g": (None, [_vp, _vp, _vp]),
+    "oslam_sort_cells": (None, [_vp, _sz]),
+    "oslam_filter_cells": (_sz, [_vp, _sz, _f, C.c_uint32]),
+    "oslam_pose_stage": (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "oslam_align_local": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
+    "oslam_align_finish": (_i, [_vp, _vp, _vp, _sz, C.c_uint32, _vp, C.POINTER(Stats)]),
+    "oslam_scene_keys": (_i, [_vp, _sz, _vp]),
+    "oslam_model_keys": (_i, [_vp, _sz, _vp]),
+    "oslam_model_bucket": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "oslam_vote_accumulator": (_i, [_vp, _vp, _sz, _vp]),
+    "oslam_last_cells": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "oslam_set_stream": (_i, [_vp]),
+    "oslam_last_error": (C.c_char_p, []),
+    "oslam_selftest_math": (_i, [_sz, C.c_uint64, C.POINTER(C.c_uint64)]),
+}
+
+
+def lib():
+    """Load liboslam_hip.so (built in-tree by __graft_entry__.build()); raise if absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise OslamError(OSLAM_E_DEVICE, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                             "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != OSLAM_OK:
+        raise OslamError(rc, lib().oslam_last_error().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = Params()
+    _check(lib().oslam_params_default(C.byref(p)))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def _cloud_args(points, normals=None):
+    """-> (xyz pointer holder, nrm pointer, n, stride, keepalive array(s))"""
+    pts = np.asarray(points)
+    if normals is None:
+        a = np.ascontiguousarray(pts, np.float32)
+        if a.ndim != 2 or a.shape[1] != 12:
+            raise ValueError("a single cloud array must be [n,12] float32 (pcl::PointNormal layout)")
+        base = a.ctypes.data
+        return C.c_void_p(base), C.c_void_p(base + 16), len(a), 48, (a,)
+    p = np.ascontiguousarray(pts, np.float32)
+    n = np.ascontiguousarray(normals, np.float32)
+    if p.ndim != 2 or p.shape[1] != 3 or n.shape != p.shape:
+        raise ValueError("points and normals must both be [n,3]")
+    return _p(p), _p(n), len(p), 12, (p, n)
+
+
+def d_dist_from_cloud(points, tau_d):
+    """d_dist = tau_d * max bbox extent (alignment.cpp:246-253)."""
+    p = np.ascontiguousarray(points, np.float32)
+    out = C.c_float(0)
+    _check(lib().oslam_d_dist_from_cloud(_p(p), len(p), p.strides[0], float(tau_d), C.byref(out)))
+    return out.value
+
+
+class Scene:
+    """Scene(cloud, d_dist, ref_point_downsample_factor=1)  (scene.h:15-16)."""
+
+    def __init__(self, points, normals=None, d_dist=None, ref_point_downsample_factor=1, params=None):
+        if d_dist is None:
+            raise TypeError("d_dist is required")
+        self._h = C.c_void_p(0)
+        xyz, nrm, n, stride, keep = _cloud_args(points, normals)
+        self.params = params if params is not None else default_params()
+        self.d_dist = float(d_dist)
+        self.df = int(ref_point_downsample_factor)
+        self.n = n
+        _check(lib().oslam_scene_create(xyz, nrm, n, stride, self.d_dist, self.df, C.byref(self.params), C.byref(self._h)))
+
+    def numPoints(self):
+        return self.n
+
+    def getHashKeys(self, ref_index):
+        """Row `ref_index` of the reference's N x N hashKeys array (scene.cu:49-54)."""
+        out = np.zeros(self.n, np.uint32)
+        _check(lib().oslam_scene_keys(self._h, int(ref_index), _p(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().oslam_scene_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model:
+    """Model(cloud, d_dist, vote_count_threshold, cpu_clustering, use_l1_norm,
+    use_averaged_clusters)  (model.h:17-19); results appear in the same fields
+    after ppf_lookup: transformations, vote_counts, max_idx / best_T."""
+
+    def __init__(self, points, normals=None, d_dist=None, vote_count_threshold=0.4, cpu_clustering=False,
+                 use_l1_norm=False, use_averaged_clusters=False, params=None):
+        if d_dist is None:
+            raise TypeError("d_dist is required")
+        self._h = C.c_void_p(0)
+        xyz, nrm, n, stride, keep = _cloud_args(points, normals)
+        self.params = params if params is not None else default_params()
+        self.params.vote_count_threshold = float(vote_count_threshold)
+        self.params.cpu_clustering = int(cpu_clustering)
+        self.params.use_l1_norm = int(use_l1_norm)
+        self.params.use_averaged_clusters = int(use_averaged_clusters)
+        self.d_dist = float(d_dist)
+        self.n = n
+        self.best_T = None
+        self.stats = None
+        _check(lib().oslam_model_create(xyz, nrm, n, stride, self.d_dist, C.byref(self.params), C.byref(self._h)))
+
+    def numPoints(self):
+        return self.n
+
+    def SetModelPointVoteWeights(self, weights):
+        w = np.ascontiguousarray(weights, np.float32)
+        _check(lib().oslam_model_set_point_weights(self._h, _p(w), len(w)))
+
+    def ppf_lookup(self, scene, allow_no_votes=False):
+        """Model::ppf_lookup (model.cu:269-306) + extraction (ppf.cu:74-93)."""
+        T = np.zeros(16, np.float32)
+        st = Stats()
+        rc = lib().oslam_align(self._h, scene._h, _p(T), C.byref(st))
+        if not (allow_no_votes and rc == OSLAM_E_NO_VOTES):
+            _check(rc)
+        self.best_T = T.reshape(4, 4)
+        self.stats = st.asdict()
+        return self.best_T
+
+    def align_local(self, scene, cap=4096):
+        cells = np.zeros(cap, CELL_DTYPE)
+        n = C.c_size_t(0)
+        lmax = C.c_uint32(0)
+        st = Stats()
+        _check(lib().oslam_align_local(self._h, scene._h, _p(cells), cap, C.byref(n), C.byref(lmax), C.byref(st)))
+        self.stats = st.asdict()
+        return cells[: n.value].copy(), int(lmax.value)
+
+    def align_finish(self, scene, cells, global_max, allow_no_votes=False):
+        cells = np.ascontiguousarray(cells, CELL_DTYPE)
+        T = np.zeros(16, np.float32)
+        st = Stats()
+        rc = lib().oslam_align_finish(self._h, scene._h, _p(cells), len(cells), int(global_max), _p(T), C.byref(st))
+        if not (allow_no_votes and rc == OSLAM_E_NO_VOTES):
+            _check(rc)
+        self.best_T = T.reshape(4, 4)
+        return self.best_T
+
+    # -- result fields of the reference's Model (model.h:92-113) --
+    def last_cells(self):
+        n = C.c_size_t(0)
+        _check(lib().oslam_last_cells(self._h, None, None, 0, C.byref(n)))
+        cells = np.zeros(n.value, CELL_DTYPE)
+        poses = np.zeros((n.value, 16), np.float32)
+        if n.value:
+            _check(lib().oslam_last_cells(self._h, _p(cells), _p(poses), n.value, C.byref(n)))
+        return cells, poses
+
+    @property
+    def transformations(self):
+        return self.last_cells()[1]
+
+    def getHashKeys(self, ref_index):
+        out = np.zeros(self.n, np.uint32)
+        _check(lib().oslam_model_keys(self._h, int(ref_index), _p(out)))
+        return out
+
+    def bucket(self, key, cap=1 << 20):
+        """Flat pair indices m_r*M + m_i stored under `key` (ParallelHashArray lookup)."""
+        out = np.zeros(cap, np.uint32)
+        n = C.c_size_t(0)
+        _check(lib().oslam_model_bucket(self._h, int(key), _p(out), cap, C.byref(n)))
+        return out[: min(n.value, cap)].copy(), n.value
+
+    def vote_accumulator(self, scene, ref_index):
+        acc = np.zeros((self.n, 32), np.uint32)
+        _check(lib().oslam_vote_accumulator(self._h, scene._h, int(ref_index), _p(acc)))
+        return acc
+
+    def close(self):
+        if self._h:
+            lib().oslam_model_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ppf_registration(scene_clouds, model_clouds, model_d_dists, ref_point_downsample_factor=1,
+                     vote_count_threshold=0.4, cpu_clustering=False, use_l1_norm=False,
+                     use_averaged_clusters=False, devUse=0, model_weights=None):
+    """ppf_registration (ppf.h:9-15): clouds are (points, normals) tuples.
+    Returns results[i][j] = 4x4 pose of model j in scene i."""
+    L = lib()
+    keep = []
+
+    def pack(clouds):
+        xs, ns, cnt = [], [], []
+        for pts, nrm in clouds:
+            p = np.ascontiguousarray(pts, np.float32)
+            q = np.ascontiguousarray(nrm, np.float32)
+            keep.extend([p, q])
+            xs.append(p.ctypes.data)
+            ns.append(q.ctypes.data)
+            cnt.append(len(p))
+        return ((C.c_void_p * len(xs))(*xs), (C.c_void_p * len(ns))(*ns), (C.c_size_t * len(cnt))(*cnt))
+
+    sx, sn, sc = pack(scene_clouds)
+    mx, mn, mc = pack(model_clouds)
+    dd = np.ascontiguousarray(model_d_dists, np.float32)
+    out = np.zeros((len(scene_clouds), len(model_clouds), 4, 4), np.float32)
+    _check(L.oslam_ppf_registration(sx, sn, sc, len(scene_clouds), mx, mn, mc, len(model_clouds), 12, _p(dd),
+                                    int(ref_point_downsample_factor), float(vote_count_threshold),
+                                    int(cpu_clustering), int(use_l1_norm), int(use_averaged_clusters),
+                                    int(devUse), None, _p(out)))
+    return out
+
+
+def ht_dist(A, B):
+    """ht_dist (linalg.cu:9-20): (|dt|, |rotation angle|)."""
+    a = np.ascontiguousarray(A, np.float32).reshape(16)
+    b = np.ascontiguousarray(B, np.float32).reshape(16)
+    out = np.zeros(2, np.float32)
+    _check(lib().oslam_ht_dist(_p(a), _p(b), _p(out)))
+    return float(out[0]), float(out[1])
+
+
+def pose_stage(cells, m_pts, m_nrm, s_pts, s_nrm, d_dist, cpu_clustering=False, use_l1_norm=False,
+               use_averaged_clusters=False, weights=None, allow_no_votes=False):
+    """Host stage only (no GPU): filtered+sorted cells -> (best T, all poses)."""
+    cells = np.ascontiguousarray(cells, CELL_DTYPE)
+    mp, mn = np.ascontiguousarray(m_pts, np.float32), np.ascontiguousarray(m_nrm, np.float32)
+    sp, sn = np.ascontiguousarray(s_pts, np.float32), np.ascontiguousarray(s_nrm, np.float32)
+    T = np.zeros(16, np.float32)
+    poses = np.zeros((len(cells), 16), np.float32)
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    rc = lib().oslam_pose_stage(_p(cells), len(cells), _p(mp), _p(mn), len(mp), _p(sp), _p(sn), len(sp),
+                                float(d_dist), int(cpu_clustering), int(use_l1_norm), int(use_averaged_clusters),
+                                _p(w) if w is not None else None, _p(T), _p(poses))
+    if not (allow_no_votes and rc == OSLAM_E_NO_VOTES):
+        if rc != OSLAM_OK:
+            raise OslamError(rc, "pose stage failed")
+    return T.reshape(4, 4), poses
+
+
+def selftest_math(n=1 << 20, seed=1):
+    bad = C.c_uint64(0)
+    _check(lib().oslam_selftest_math(int(n), int(seed), C.byref(bad)))
+    return int(bad.value)
+
+
+def set_stream(stream_ptr):
+    _check(lib().oslam_set_stream(C.c_void_p(stream_ptr or 0)))

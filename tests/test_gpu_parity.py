@@ -1,0 +1,168 @@
+"""GPU parity: the HIP path through the C-ABI against the CPU oracle on the same
+seeded clouds.  Integer results (keys, buckets, accumulators, peak cells) must be
+identical; the pose is produced by the same host stage from identical cells, so
+it is compared exactly too."""
+import numpy as np
+import pytest
+
+from conftest import cells_equal, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_float_path_matches_host(ppf, built_lib):
+    # pm_acosf / pm_atan2f / quantisation / alpha bin: 4M pseudo-random inputs, GPU vs host bits
+    assert ppf.selftest_math(1 << 22, seed=7) == 0
+
+
+def test_scene_and_model_keys_bit_exact(ppf, oracle, built_lib, case_small):
+    c = case_small
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"])
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+    for r in (0, 1, 17, len(c["sp"]) - 1):
+        assert np.array_equal(sc.getHashKeys(r), oracle.ppf_row_keys(c["sp"], c["sn"], r, c["d"]))
+    for r in (0, 5, len(c["mp"]) - 1):
+        assert np.array_equal(mo.getHashKeys(r), oracle.ppf_row_keys(c["mp"], c["mn"], r, c["d"]))
+
+
+def test_keys_with_degenerate_geometry(ppf, oracle, built_lib):
+    # duplicate points (|d| = 0 -> NaN angles), parallel/antiparallel and identical
+    # non-unit normals (acosf argument rounds past 1 -> NaN bytes hashed), zero normal
+    rng = np.random.default_rng(5)
+    p = rng.uniform(-1, 1, (96, 3)).astype(np.float32)
+    n = rng.normal(size=(96, 3)).astype(np.float32)
+    p[10] = p[3]
+    n[20:40] = np.float32([0.6, 0.0, 0.8])
+    n[40:50] = np.float32([0.3, 0.1, 0.7])
+    n[50] = 0
+    p[60:70, 2] = 0
+    n[60:70] = np.float32([0, 0, 1])
+    p[70] = p[71] + np.float32([0, 0, 1e-7])
+    d = 0.07
+    sc = ppf.Scene(p, n, d_dist=d)
+    for r in range(0, 96, 5):
+        assert np.array_equal(sc.getHashKeys(r), oracle.ppf_row_keys(p, n, r, d)), r
+
+
+def test_model_table_buckets(ppf, oracle, built_lib, case_small):
+    c = case_small
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+    _, keys = oracle.ppf_all_pairs(c["mp"], c["mn"], 1, c["d"], want_ppf=False)
+    flat = keys.reshape(-1)
+    uniq, counts = np.unique(flat, return_counts=True)
+    rng = np.random.default_rng(0)
+    pick = rng.choice(len(uniq), size=40, replace=False)
+    for u in pick:
+        k = int(uniq[u])
+        if k == 0:
+            continue
+        got, n = mo.bucket(k)
+        want = np.nonzero(flat == k)[0].astype(np.uint32)
+        assert n == counts[u] and np.array_equal(got, want)
+    assert mo.bucket(0x12345)[1] == int((flat == 0x12345).sum())
+
+
+def test_accumulator_exact(ppf, oracle, built_lib, case_small):
+    c = case_small
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"])
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+    for r in (0, 3, 250, 499):
+        got = mo.vote_accumulator(sc, r)
+        want = oracle.accumulator_for_ref(c["mp"], c["mn"], c["sp"], c["sn"], r, c["d"])
+        assert np.array_equal(got, want), r
+
+
+def _align_and_compare(ppf, oracle, c, df=1, **flags):
+    par = ppf.default_params()
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=df, params=par)
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par, **flags)
+    T = mo.ppf_lookup(sc)
+    cells, poses = mo.last_cells()
+    ocells, ost = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], df, c["d"], 0.4)
+    assert cells_equal(cells, ocells)
+    st = mo.stats
+    for k in ("num_scene_ppfs", "num_hits", "num_votes", "num_unique_votes", "num_model_keys", "max_count"):
+        assert st[k] == ost[k], k
+    assert st["num_top"] == ost["num_top"]
+    rc, To = oracle.pose_from_cells(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"],
+                                    cpu_clustering=flags.get("cpu_clustering", False),
+                                    use_l1_norm=flags.get("use_l1_norm", False),
+                                    use_averaged_clusters=flags.get("use_averaged_clusters", False))
+    assert np.array_equal(T, To)
+    return T
+
+
+def test_align_matches_oracle(ppf, oracle, built_lib, case_small):
+    T = _align_and_compare(ppf, oracle, case_small)
+    dt, dr = ppf.ht_dist(T, case_small["truth"])
+    # the reference itself is bin-accurate only (D_ANGLE0 = 12 deg, d_dist): its own
+    # acceptance test is 12 deg / 0.1 diameter (alignment.cpp:141-144)
+    assert dr < np.deg2rad(12) and dt < 0.1 * 3.8
+
+
+@pytest.mark.parametrize("flags", [dict(cpu_clustering=True), dict(use_l1_norm=True),
+                                   dict(use_averaged_clusters=True)])
+def test_align_flags(ppf, oracle, built_lib, case_small, flags):
+    _align_and_compare(ppf, oracle, case_small, **flags)
+
+
+def test_align_df_and_ragged_sizes(ppf, oracle, built_lib, synth):
+    # S not a multiple of the 1024-thread tile, df = 3 (last reference index ragged)
+    c = make_case(synth, 150, 1031, 2003)
+    _align_and_compare(ppf, oracle, c, df=3)
+
+
+def test_align_two_slices(ppf, oracle, built_lib, case_two_slices):
+    # M = 1300 -> two model slices; cells from both slices must be merged exactly
+    _align_and_compare(ppf, oracle, case_two_slices, df=10)
+
+
+def test_sharded_align_equals_single(ppf, oracle, built_lib, case_small):
+    c = case_small
+    world = 3
+    all_cells, gmax = [], 0
+    mo = None
+    for rank in range(world):
+        par = ppf.default_params(shard_rank=rank, shard_world=world)
+        sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=2, params=par)
+        mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
+        cells, lmax = mo.align_local(sc, cap=1 << 16)
+        all_cells.append(cells)
+        gmax = max(gmax, lmax)
+    T = mo.align_finish(sc, np.concatenate(all_cells), gmax)
+    ocells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 2, c["d"], 0.4)
+    rc, To = oracle.pose_from_cells(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"])
+    assert cells_equal(mo.last_cells()[0], ocells)
+    assert np.array_equal(T, To)
+
+
+def test_no_match_and_bad_arguments(ppf, built_lib, synth):
+    mp, mn = synth.make_model(0, 64)
+    d = synth.d_dist_for(mp, 0.05)
+    # a scene far smaller than one distance bin of interest: two points 100 diameters apart
+    sp = np.float32([[0, 0, 0], [400, 0, 0], [0, 400, 0]])
+    sn = np.float32([[0, 0, 1], [0, 1, 0], [1, 0, 0]])
+    mo = ppf.Model(mp, mn, d_dist=d)
+    sc = ppf.Scene(sp, sn, d_dist=d)
+    T = mo.ppf_lookup(sc, allow_no_votes=True)
+    assert np.all(T == 0) and mo.stats["num_votes"] == 0
+    with pytest.raises(ppf.OslamError):
+        mo.ppf_lookup(sc)                       # OSLAM_E_NO_VOTES is reported, not swallowed
+    with pytest.raises(ppf.OslamError):
+        ppf.Model(mp[:1], mn[:1], d_dist=d)     # n < 2
+    with pytest.raises(ppf.OslamError):
+        ppf.Scene(sp, sn, d_dist=0.0)
+    sc2 = ppf.Scene(sp, sn, d_dist=2 * d)
+    with pytest.raises(ppf.OslamError):
+        mo.ppf_lookup(sc2)                      # d_dist mismatch (ppf.cu:64-67)
+
+
+def test_ppf_registration_entry_point(ppf, oracle, built_lib, synth):
+    a = make_case(synth, 120, 400, 2004)
+    b = make_case(synth, 140, 400, 2005, model_id=1)
+    res = ppf.ppf_registration([(a["sp"], a["sn"])], [(a["mp"], a["mn"]), (b["mp"], b["mn"])],
+                               [a["d"], b["d"]], ref_point_downsample_factor=2)
+    for j, c in enumerate((a, b)):
+        ocells, _ = oracle.votes_fused(c["mp"], c["mn"], a["sp"], a["sn"], 2, c["d"], 0.4)
+        rc, To = oracle.pose_from_cells(ocells, c["mp"], c["mn"], a["sp"], a["sn"], c["d"])
+        assert np.array_equal(res[0, j], To)
