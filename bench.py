@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X.
+
+Metric (BASELINE.json): scene PPF votes/sec, 5k-point model vs 100k-point scene.
+A "step" is one pass of the hot path (Model::ppf_lookup: scene pair keys -> table
+probe -> votes -> peak extraction -> pose) of ONE resident model table against ONE
+scene already resident in HBM.  value = scene PPFs (valid ordered pairs
+(reference point r, i != r), each keyed, probed and fully voted) processed by all
+ranks per second.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU; scene reference points are dealt round-robin to
+ranks (no data-path collective); per step an RCCL all-reduce(MAX) of the local
+vote maximum and an all-gather of fixed-size peak records, then the host stage.
+Weak scaling: ref_point_df = 8 / N keeps 12.5k reference points per GPU.
+
+One JSON line on stdout (rank 0); progress goes to stderr.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+RECORD_CAP = 4096        # peak records all-gathered per GPU (16 B each = 64 KiB)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model-points", type=int, default=5000)
+    ap.add_argument("--scene-points", type=int, default=100000)
+    ap.add_argument("--tau-d", type=float, default=0.025)
+    ap.add_argument("--vote-mode", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--df", type=int, default=0, help="ref_point_df; 0 = 8 // gpus (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    pkg = importlib.import_module("objective-slam_amd")
+    ppf, synth = pkg.ppf, pkg.synth
+
+    M, S = args.model_points, args.scene_points
+    df = args.df if args.df > 0 else max(1, 8 // world)
+    mp, mn = synth.make_model(0, M)
+    d_dist = synth.d_dist_for(mp, args.tau_d)
+    sp, sn, poses = synth.make_scene([0], S, 2002, instance_points=M, noise_sigma=0.1 * d_dist)
+    diam = synth.bbox_extent(mp)
+
+    mode = ppf.VOTE_FAST if args.vote_mode == "fast" else ppf.VOTE_EXACT
+    par = ppf.default_params(dev=local_rank, shard_rank=rank, shard_world=world, vote_mode=mode)
+    stream = torch.cuda.current_stream()
+    ppf.set_stream(stream.cuda_stream)
+    t0 = time.time()
+    model = ppf.Model(mp, mn, d_dist=d_dist, params=par)       # table resident in HBM
+    t_build = time.time() - t0
+    scene = ppf.Scene(sp, sn, d_dist=d_dist, ref_point_downsample_factor=df, params=par)   # resident in HBM
+    log("[rank %d] model build %.3fs, d_dist %.5f, df %d" % (rank, t_build, d_dist, df))
+
+    rec_buf = torch.zeros(RECORD_CAP * 2, dtype=torch.int64, device="cuda")
+    gathered = torch.zeros(world * RECORD_CAP * 2, dtype=torch.int64, device="cuda") if world > 1 else None
+    meta = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def step():
+        if world == 1:
+            T = model.ppf_lookup(scene)
+            return T, dict(model.stats)
+        cells, lmax = model.align_local(scene, cap=RECORD_CAP)
+        st = dict(model.stats)
+        host = np.zeros(RECORD_CAP * 2, np.int64)
+        host[: 2 * len(cells)] = cells.view(np.int64).reshape(-1) if len(cells) else []
+        rec_buf.copy_(torch.from_numpy(host), non_blocking=False)
+        meta[0] = lmax
+        dist.all_reduce(meta[:1], op=dist.ReduceOp.MAX)                  # global vote maximum
+        dist.all_gather_into_tensor(gathered, rec_buf)                   # per-GPU top pose votes
+        allrec = gathered.cpu().numpy().view(ppf.CELL_DTYPE)
+        allrec = allrec[allrec["count"] > 0]
+        T = model.align_finish(scene, allrec, int(meta[0].item()))       # host-side clustering
+        return T, st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    t0 = time.perf_counter()
+    stats_acc, T = [], None
+    for _ in range(args.steps):
+        T, st = step()
+        stats_acc.append(st)
+    ev1.record(stream)
+    sync()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ppfs = torch.tensor([float(sum(s["num_scene_ppfs"] for s in stats_acc)),
+                         float(sum(s["num_votes"] for s in stats_acc))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ppfs, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_ppfs, total_votes = float(ppfs[0].item()), float(ppfs[1].item())
+
+    if rank == 0:
+        st = stats_acc[-1]
+        ms_vote = float(np.mean([s["ms_vote"] for s in stats_acc]))      # HIP events on the launch stream
+        # algorithmic bytes of one vote launch: scene points + normals read once,
+        # 8 B per probed scene pair, 8 B per vote (one model-pair entry), 16 B per emitted record
+        bytes_alg = 24.0 * S + 8.0 * st["num_scene_ppfs"] + 8.0 * st["num_votes"] + 16.0 * st["num_emitted"]
+        achieved = bytes_alg / (ms_vote * 1e-3) / 1e9
+        dt, dr = ppf.ht_dist(T, poses[0][1])
+        out = {
+            "metric": "scene_ppf_votes_per_sec",
+            "value": total_ppfs / elapsed,
+            "unit": "scene PPFs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "5k-point model vs 100k-point scene (BASELINE.json metric config), "
+                                   "one resident model table, Model::ppf_lookup per step",
+                       "model_points": M, "scene_points": S, "tau_d": args.tau_d, "d_dist": d_dist,
+                       "ref_point_df": df, "ref_points_per_gpu": int(st["num_scene_ppfs"] // (S - 1)),
+                       "vote_mode": args.vote_mode, "vote_count_threshold": 0.4,
+                       "parallelism": "scene-ref-shard x%d" % world},
+            "vote_increments_per_sec": total_votes / elapsed,
+            "per_step": {"scene_ppfs": st["num_scene_ppfs"], "hits": st["num_hits"], "votes": st["num_votes"],
+                         "nonempty_cells": st["num_unique_votes"], "model_keys": st["num_model_keys"],
+                         "max_cell": st["max_count"], "emitted_records": st["num_emitted"],
+                         "top_cells": st.get("num_top", 0)},
+            "pose": {"rot_err_deg": float(np.degrees(dr)), "trans_err_frac_diam": dt / diam,
+                     "ok_at_reference_criterion_12deg_0.1diam": bool(dr < np.radians(12) and dt < 0.1 * diam)},
+            "model_build_s": t_build,
+            "roofline": {"bound": "hbm", "kernel": "k_vote", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "alg_bytes_per_launch": bytes_alg, "launch_ms": ms_vote,
+                         "torch_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mp, mn, sp, sn, df, d_dist)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(mp, mn, sp, sn, df, d_dist):
+    """The CPU oracle's fused path (kind "port"; no reference build exists here) on a bounded
+    sample of the same workload: the first 8*cores reference points, OpenMP over them."""
+    from oracle import oracle as O
+    # a 1-GPU box shares its host: use at most its 16-core share (the affinity mask shows every core)
+    cores = min(16, len(os.sched_getaffinity(0)))
+    t0 = time.time()
+    fm = O.FusedModel(mp, mn, d_dist)
+    log("[cpu baseline] model table on the CPU: %.1fs" % (time.time() - t0))
+    n_ref = 8 * cores
+    t0 = time.perf_counter()
+    _, st = fm.votes(sp, sn, df, ref_limit=n_ref, threads=cores)
+    el = time.perf_counter() - t0
+    fm.close()
+    return {"value": st["num_scene_ppfs"] / el, "unit": "scene PPFs/s", "cores": cores, "kind": "port",
+            "sample": "first %d scene reference points of the same workload (%d scene PPFs, %d votes) in %.1f s; "
+                      "model table build excluded" % (n_ref, st["num_scene_ppfs"], st["num_votes"], el),
+            "vote_increments_per_sec": st["num_votes"] / el}
+
+
+if __name__ == "__main__":
+    main()

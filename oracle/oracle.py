@@ -56,6 +56,12 @@ def lib():
     L.orc_votes_fused.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                   C.c_long, C.c_long, C.c_long, C.c_int, C.POINTER(C.c_size_t),
                                   C.POINTER(Stats)]
+    L.orc_fused_create.restype = C.c_void_p
+    L.orc_fused_create.argtypes = [vp, vp, C.c_int, C.c_float]
+    L.orc_fused_free.argtypes = [vp]
+    L.orc_fused_votes.restype = C.c_void_p
+    L.orc_fused_votes.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_long, C.c_long,
+                                  C.c_long, C.c_int, C.POINTER(C.c_size_t), C.POINTER(Stats)]
     L.orc_accumulator_for_ref.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, vp]
     L.orc_trans_model_scene.restype = C.c_uint
     L.orc_trans_calc2.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp]
@@ -152,6 +158,35 @@ def votes_fused(mp, mn, sp, sn, df, d_dist, thresh=0.4, ref_begin=0, ref_step=1,
                                 C.byref(n_out), C.byref(st))
     cells = _cells_from(ptr, n_out.value)
     return cells, st.asdict()
+
+
+class FusedModel:
+    """Model table built once on the CPU; votes() can then be timed on its own."""
+
+    def __init__(self, mp, mn, d_dist):
+        self.mp, self.mn = _c32(mp), _c32(mn)
+        self.d_dist = float(d_dist)
+        self.h = lib().orc_fused_create(_p(self.mp), _p(self.mn), len(self.mp), self.d_dist)
+
+    def votes(self, sp, sn, df, thresh=0.4, ref_begin=0, ref_step=1, ref_limit=-1, threads=0):
+        sp, sn = _c32(sp), _c32(sn)
+        n_out = C.c_size_t(0)
+        st = Stats()
+        ptr = lib().orc_fused_votes(self.h, _p(sp), _p(sn), len(sp), int(df), self.d_dist, float(thresh),
+                                    int(ref_begin), int(ref_step), int(ref_limit), int(threads),
+                                    C.byref(n_out), C.byref(st))
+        return _cells_from(ptr, n_out.value), st.asdict()
+
+    def close(self):
+        if self.h:
+            lib().orc_fused_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def accumulator_for_ref(mp, mn, sp, sn, s_r, d_dist):

@@ -460,17 +460,30 @@ void orc_accumulator_for_ref(const orc_f3 *mp, const orc_f3 *mn, int M, const or
     fused_model_free(&fm);
 }
 
-orc_cell *orc_votes_fused(const orc_f3 *mp, const orc_f3 *mn, int M, const orc_f3 *sp,
-                          const orc_f3 *sn, int S, int df, float d_dist, float thresh,
-                          long ref_begin, long ref_step, long ref_limit, int threads,
+void *orc_fused_create(const orc_f3 *mp, const orc_f3 *mn, int M, float d_dist)
+{
+    fused_model *fm = (fused_model *)calloc(1, sizeof *fm);
+    fused_model_build(fm, mp, mn, M, d_dist);
+    return fm;
+}
+
+void orc_fused_free(void *h)
+{
+    if (!h) return;
+    fused_model_free((fused_model *)h);
+    free(h);
+}
+
+orc_cell *orc_fused_votes(void *h, const orc_f3 *sp, const orc_f3 *sn, int S, int df, float d_dist,
+                          float thresh, long ref_begin, long ref_step, long ref_limit, int threads,
                           size_t *n_out, orc_stats *st)
 {
+    const fused_model *fmp = (const fused_model *)h;
+    const int M = fmp->M;
     orc_stats local;
     if (!st) st = &local;
     memset(st, 0, sizeof *st);
-    fused_model fm;
-    fused_model_build(&fm, mp, mn, M, d_dist);
-    st->num_model_keys = fm.tab.n_unique;
+    st->num_model_keys = fmp->tab.n_unique;
 
     long n_ref_all = (S + df - 1) / df;
     if (ref_step < 1) ref_step = 1;
@@ -494,7 +507,7 @@ orc_cell *orc_votes_fused(const orc_f3 *mp, const orc_f3 *mn, int M, const orc_f
         for (long kk = 0; kk < n_ref; kk++) {
             int s_r = (int)(df * (ref_begin + kk * ref_step));
             memset(acc, 0, sizeof(uint32_t) * 32 * (size_t)M);
-            fused_accumulate(&fm, sp, sn, S, s_r, d_dist, acc, &hits, &votes);
+            fused_accumulate(fmp, sp, sn, S, s_r, d_dist, acc, &hits, &votes);
             ppfs += (uint64_t)(S - 1);
             uint32_t lmax = 0;
             for (size_t c = 0; c < (size_t)M * 32; c++) {
@@ -523,12 +536,23 @@ orc_cell *orc_votes_fused(const orc_f3 *mp, const orc_f3 *mn, int M, const orc_f
         }
         free(acc);
     }
-    fused_model_free(&fm);
     st->num_scene_ppfs = ppfs;
     st->num_hits = hits;
     st->num_votes = votes;
     st->num_unique_votes = uniq;
     return threshold_cells(cells, ncell, thresh, n_out, st);
+}
+
+orc_cell *orc_votes_fused(const orc_f3 *mp, const orc_f3 *mn, int M, const orc_f3 *sp,
+                          const orc_f3 *sn, int S, int df, float d_dist, float thresh,
+                          long ref_begin, long ref_step, long ref_limit, int threads,
+                          size_t *n_out, orc_stats *st)
+{
+    void *h = orc_fused_create(mp, mn, M, d_dist);
+    orc_cell *cells = orc_fused_votes(h, sp, sn, S, df, d_dist, thresh, ref_begin, ref_step, ref_limit,
+                                      threads, n_out, st);
+    orc_fused_free(h);
+    return cells;
 }
 
 /* ---------------------------------------------------------------------------

@@ -100,6 +100,12 @@ orc_cell *orc_votes_fused(const orc_f3 *mp, const orc_f3 *mn, int M, const orc_f
                           const orc_f3 *sn, int S, int df, float d_dist, float thresh,
                           long ref_begin, long ref_step, long ref_limit, int threads,
                           size_t *n_out, orc_stats *st);
+/* the same with the model table built once (CPU-baseline timing excludes the build) */
+void *orc_fused_create(const orc_f3 *mp, const orc_f3 *mn, int M, float d_dist);
+orc_cell *orc_fused_votes(void *h, const orc_f3 *sp, const orc_f3 *sn, int S, int df, float d_dist,
+                          float thresh, long ref_begin, long ref_step, long ref_limit, int threads,
+                          size_t *n_out, orc_stats *st);
+void orc_fused_free(void *h);
 /* dense accumulator [M][32] of one scene reference point (fused path) */
 void orc_accumulator_for_ref(const orc_f3 *mp, const orc_f3 *mn, int M, const orc_f3 *sp,
                              const orc_f3 *sn, int S, int s_r, float d_dist, uint32_t *acc);
