@@ -126,6 +126,10 @@ struct oslam_model {
     uint64_t num_model_keys;
     float *weights;
     /* align workspace */
+    oslamk_hit *d_hits;               /* per-reference hit lists of one batch */
+    size_t hits_bytes;
+    uint32_t *d_hit_count;
+    size_t hit_count_cap;
     oslamk_counters *d_counters;
     oslamk_cell *d_out;
     uint32_t out_cap;
@@ -216,6 +220,9 @@ void oslam_model_destroy(oslam_model *m)
     if (m->table.slots) (void)hipFree(m->table.slots);
     if (m->exact) (void)hipFree(m->exact);
     if (m->fast) (void)hipFree(m->fast);
+    if (m->table.ukeys) (void)hipFree(m->table.ukeys);
+    if (m->d_hits) (void)hipFree(m->d_hits);
+    if (m->d_hit_count) (void)hipFree(m->d_hit_count);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
     free(m->h_out);
@@ -282,9 +289,21 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
         if (cap >= (1u << 26)) { rc = fail(OSLAM_E_LIMIT, "model hash table would exceed 2^26 slots per slice"); goto done; }
     }
     KCHK(oslamk_table_scan(m->table, d_small + 65, g_stream));
-    KCHK(oslamk_table_mark_first(m->table, d_small + 66, g_stream));
+    /* union of all slices' keys, kept at most a quarter full */
+    {
+        uint32_t sum = 0, lg = 16;
+        for (s = 0; s < n_slices; s++) sum += h_small[s];
+        while ((1u << lg) < 4u * sum && lg < 30) lg++;
+        m->table.ucap = 1u << lg;
+        m->table.ushift = 32 - lg;
+        HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)m->table.ucap));
+        HIPCHK(hipMemsetAsync(m->table.ukeys, 0, sizeof(uint32_t) * (size_t)m->table.ucap, (hipStream_t)g_stream));
+        HIPCHK(hipMemsetAsync(d_small + 64, 0, sizeof(uint32_t), (hipStream_t)g_stream));
+        KCHK(oslamk_union_build(m->table, d_small + 66, d_small + 64, g_stream));
+    }
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
     HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
+    if (h_small[64]) { rc = fail(OSLAM_E_LIMIT, "union key table overflow"); goto done; }
     m->n_entries = h_small[65];
     m->num_model_keys = (uint64_t)h_small[66] + 1;    /* + the key-0 bucket of the n self pairs */
     n_pairs = m->n_entries ? m->n_entries : 1;
@@ -394,14 +413,44 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
     return OSLAM_OK;
 }
 
-/* run the vote kernel over the scene's shard; leaves emitted cells in m->h_out */
+/* scratch for the hit lists: up to 8 GiB, at least one reference point's worth */
+static int ensure_hit_scratch(oslam_model *m, const oslam_scene *s, int *batch_out)
+{
+    int rc = OSLAM_OK;
+    const size_t per_ref = (size_t)s->c.n * sizeof(oslamk_hit);
+    size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)8 << 30;
+    size_t batch;
+    if (want > cap) want = cap;
+    if (want < per_ref) want = per_ref;
+    if (m->hits_bytes < want) {
+        if (m->d_hits) { (void)hipFree(m->d_hits); m->d_hits = NULL; m->hits_bytes = 0; }
+        HIPCHK(hipMalloc((void **)&m->d_hits, want));
+        m->hits_bytes = want;
+    }
+    batch = m->hits_bytes / per_ref;
+    if (batch > (size_t)s->n_ref) batch = (size_t)(s->n_ref > 0 ? s->n_ref : 1);
+    if (batch > 65535) batch = 65535;            /* grid.y of the scene-key kernel */
+    if (m->hit_count_cap < batch) {
+        if (m->d_hit_count) { (void)hipFree(m->d_hit_count); m->d_hit_count = NULL; m->hit_count_cap = 0; }
+        HIPCHK(hipMalloc((void **)&m->d_hit_count, sizeof(uint32_t) * batch));
+        m->hit_count_cap = batch;
+    }
+    *batch_out = (int)batch;
+done:
+    return rc;
+}
+
+/* scene keys + votes over the scene's shard, in batches of reference points; leaves emitted
+ * cells in m->d_out */
 static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
                      float *ms_out, uint32_t *launches)
 {
-    int rc = OSLAM_OK;
+    int rc = OSLAM_OK, batch = 1, first;
     hipEvent_t e0 = NULL, e1 = NULL;
     oslamk_vote_args a;
     hipStream_t st = (hipStream_t)g_stream;
+    rc = ensure_hit_scratch(m, s, &batch);
+    if (rc != OSLAM_OK) return rc;
     memset(&a, 0, sizeof a);
     a.scene = s->c.k;
     a.ref_idx = s->d_ref_idx;
@@ -419,19 +468,26 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.out_cap = m->out_cap;
     a.acc_dump = NULL;
     a.dump_ref = -1;
-    a.first_ref = 0;
-    a.n_launch = s->n_ref;
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST && m->fast) ? 1 : 0;
+    a.hits = m->d_hits;
+    a.hit_count = m->d_hit_count;
+    a.hit_stride = (size_t)s->c.n;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
     HIPCHK(hipEventRecord(e0, st));
-    KCHK(oslamk_vote(&a, g_stream));
+    for (first = 0; first < s->n_ref; first += batch) {
+        a.first_ref = first;
+        a.n_launch = s->n_ref - first < batch ? s->n_ref - first : batch;
+        HIPCHK(hipMemsetAsync(m->d_hit_count, 0, sizeof(uint32_t) * (size_t)a.n_launch, st));
+        KCHK(oslamk_scene_hits(&a, g_stream));
+        KCHK(oslamk_vote(&a, g_stream));
+        if (launches) *launches += 1;
+    }
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipMemcpyAsync(cnt, m->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, e0, e1));
-    if (launches) *launches += 1;
 done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
@@ -725,6 +781,16 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
     a.first_ref = 0;
     a.n_launch = 1;
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST && m->fast) ? 1 : 0;
+    {
+        int batch = 1;
+        rc = ensure_hit_scratch(m, s, &batch);
+        if (rc != OSLAM_OK) goto done;
+    }
+    a.hits = m->d_hits;
+    a.hit_count = m->d_hit_count;
+    a.hit_stride = (size_t)s->c.n;
+    HIPCHK(hipMemsetAsync(m->d_hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));
+    KCHK(oslamk_scene_hits(&a, g_stream));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), (hipStream_t)g_stream));
     KCHK(oslamk_vote(&a, g_stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));

@@ -21,7 +21,7 @@ extern "C" {
 typedef struct oslamk_slot {
     uint32_t key;              /* 0 = empty (key 0 is never stored: kernel.cu:491) */
     uint32_t start;            /* first entry of the bucket in the entry arrays */
-    uint32_t len;              /* bucket length; bit 31: no lower slice holds this key */
+    uint32_t len;              /* bucket length */
     uint32_t cur;              /* fill cursor (== len after the build) */
 } oslamk_slot;
 
@@ -49,6 +49,9 @@ typedef struct oslamk_table {
     uint32_t cap;              /* power of two */
     uint32_t shift;            /* 32 - log2(cap) */
     int n_slices;
+    uint32_t *ukeys;           /* [ucap] union of the keys of all slices (0 = empty) */
+    uint32_t ucap;             /* power of two */
+    uint32_t ushift;
 } oslamk_table;
 
 /* Counters one vote launch accumulates (device memory, zeroed by the host). */
@@ -76,13 +79,17 @@ int oslamk_model_count(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_ta
                        uint32_t *n_unique, uint32_t *overflow, void *stream);
 /* exclusive scan of slot.len over all slots -> slot.start; total written to *total_out */
 int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
-/* mark slots whose key is in no lower slice (bit 31 of len); counts them in *n_first */
-int oslamk_table_mark_first(oslamk_table t, uint32_t *n_first, void *stream);
+/* fill t.ukeys with every distinct key; *n_keys = number of distinct keys */
+int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream);
 /* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed).
  * fast may be NULL. */
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
                       const float *tmg, oslamk_entry_exact *exact, oslamk_entry_fast *fast,
                       void *stream);
+
+typedef struct oslamk_hit {
+    uint32_t key, vy_bits, vz_bits, index;
+} oslamk_hit;
 
 typedef struct oslamk_vote_args {
     oslamk_cloud scene;
@@ -103,8 +110,17 @@ typedef struct oslamk_vote_args {
     int first_ref;             /* launch covers reference ordinals first_ref .. first_ref+n_launch-1 */
     int n_launch;
     int mode;                  /* 0 exact, 1 fast */
+    /* per-reference hit lists of this batch (written by oslamk_scene_hits, read by oslamk_vote):
+     * hits[ref_local * hit_stride + k] = {key, vy bits, vz bits, scene index}, k < hit_count[ref_local] */
+    oslamk_hit *hits;
+    uint32_t *hit_count;
+    size_t hit_stride;
 } oslamk_vote_args;
 
+/* scene pair keys -> per-reference hit lists, for reference ordinals first_ref..+n_launch-1;
+ * hit_count[0..n_launch) must be zero on entry */
+int oslamk_scene_hits(const oslamk_vote_args *a, void *stream);
+/* votes of the same batch (needs the hit lists) */
 int oslamk_vote(const oslamk_vote_args *a, void *stream);
 
 /* device self-test: out_acos[i] = pm_acosf(x[i]); out_atan2[i] = pm_atan2f(y[i], x2[i]);

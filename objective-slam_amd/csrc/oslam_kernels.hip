@@ -7,10 +7,13 @@
  * (pcl/alignment/src/cuda/{scene,model}.cu) is fused here:
  *   model build : pair key -> per-slice open-addressing table -> bucketed
  *                 16-byte pair entries (two counting passes, no sort);
+ *   scene keys  : one thread per scene pair (reference r, point i): key ->
+ *                 probe of the union table of all model keys -> per-reference
+ *                 hit list (key, T_s_g*s_i) written by wave-aggregated appends;
  *   voting      : one workgroup per (scene reference point, model slice):
- *                 pair key -> table probe -> wave-cooperative sweep of the
- *                 bucket -> LDS accumulator [1024 model refs][32 alpha bins]
- *                 -> in-kernel peak extraction.
+ *                 hit -> slice table probe -> wave-cooperative, prefetched sweep
+ *                 of the bucket -> LDS accumulator [1024 model refs][32 alpha
+ *                 bins] -> in-kernel peak extraction.
  */
 #include <hip/hip_runtime.h>
 
@@ -118,31 +121,23 @@ __global__ __launch_bounds__(1024) void k_table_scan(oslamk_table t, uint32_t *t
     }
 }
 
-/* bit 31 of len: no lower slice holds this key (so hits are counted once) */
-__global__ void k_table_mark_first(oslamk_table t, uint32_t *n_first)
+/* union table: every key of every slice once (what the scene-key kernel probes);
+ * *n_keys counts the distinct keys */
+__global__ void k_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow)
 {
     size_t total = (size_t)t.n_slices * t.cap;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     uint32_t key = t.slots[idx].key;
     if (key == 0) return;
-    int slice = (int)(idx / t.cap);
-    uint32_t mask = t.cap - 1;
-    bool first = true;
-    for (int s = 0; s < slice && first; s++) {
-        const oslamk_slot *tab = t.slots + (size_t)s * t.cap;
-        uint32_t slot = slot_of(key, t.shift);
-        for (uint32_t probe = 0; probe < t.cap; probe++) {
-            uint32_t k = tab[slot].key;
-            if (k == key) { first = false; break; }
-            if (k == 0) break;
-            slot = (slot + 1) & mask;
-        }
+    uint32_t mask = t.ucap - 1, slot = slot_of(key, t.ushift);
+    for (uint32_t probe = 0; probe < t.ucap; probe++) {
+        uint32_t old = atomicCAS(&t.ukeys[slot], 0u, key);
+        if (old == 0u) atomicAdd(n_keys, 1u);
+        if (old == 0u || old == key) return;
+        slot = (slot + 1) & mask;
     }
-    if (first) {
-        t.slots[idx].len |= 0x80000000u;
-        atomicAdd(n_first, 1u);
-    }
+    atomicExch(overflow, 1u);
 }
 
 /* pass 2: same pairs, written into their buckets */
@@ -213,6 +208,120 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
+/* A chunk of U x 64 model-pair entries held in registers by one wave. */
+template <int MODE>
+struct Chunk;
+
+template <>
+struct Chunk<0> {                      /* exact mode: 16-byte entries */
+    static constexpr int U = 4;
+    uint4 v[U];
+    __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
+                                         uint32_t ln, int lane)
+    {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = off + u * WAVE + lane;
+            if (idx < ln) v[u] = *reinterpret_cast<const uint4 *>(&a.exact[(size_t)st + idx]);
+        }
+    }
+    __device__ __forceinline__ void vote(uint32_t *acc, uint32_t m_base, uint32_t off, uint32_t ln,
+                                         int lane, float vy, float vz) const
+    {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = off + u * WAVE + lane;
+            if (idx < ln) {
+                const unsigned bin = pc_alpha_bin_exact(__builtin_bit_cast(float, v[u].y),
+                                                        __builtin_bit_cast(float, v[u].z), vy, vz);
+                if (bin < OSLAMK_NBIN) atomicAdd(&acc[(v[u].x - m_base) * OSLAMK_NBIN + bin], 1u);
+            }
+        }
+    }
+};
+
+template <>
+struct Chunk<1> {                      /* fast mode: 8-byte entries */
+    static constexpr int U = 8;
+    uint2 v[U];
+    __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
+                                         uint32_t ln, int lane)
+    {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = off + u * WAVE + lane;
+            if (idx < ln) v[u] = *reinterpret_cast<const uint2 *>(&a.fast[(size_t)st + idx]);
+        }
+    }
+    __device__ __forceinline__ void vote(uint32_t *acc, uint32_t m_base, uint32_t off, uint32_t ln,
+                                         int lane, float cs, float) const
+    {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = off + u * WAVE + lane;
+            if (idx < ln) {
+                float t = cs - __builtin_bit_cast(float, v[u].y);   /* in [15, 75] */
+                t = t >= 30.0f ? t - 30.0f : t;
+                t = t >= 30.0f ? t - 30.0f : t;
+                const unsigned bin = (unsigned)(int)t;
+                if (bin < OSLAMK_NBIN) atomicAdd(&acc[(v[u].x - m_base) * OSLAMK_NBIN + bin], 1u);
+            }
+        }
+    }
+};
+
+/* Scene::Scene's key pass (scene.cu:24-55: K1 ppf_kernel + K2 ppf_hash_kernel) fused with
+ * the lookup of model.cu:96-97: one thread per scene pair (reference point r, point i).
+ * Pairs whose key is in the model (union of all slices) are appended to r's hit list as
+ * {key, (T_s_g*s_i).y, (T_s_g*s_i).z, i}; one atomic per wave reserves the slots.
+ * grid (ceil(S/256), refs in this batch). */
+__global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
+{
+    const int ref_local = blockIdx.y;
+    const int ref_ord = a.first_ref + ref_local;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int S = a.scene.n;
+    const uint32_t r = a.ref_idx[ref_ord];
+    bool hit = false;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (i < S && (uint32_t)i != r) {
+        const float nrx = a.scene.nx[r], nry = a.scene.ny[r], nrz = a.scene.nz[r];
+        float x, y, z;
+        const uint32_t key = cloud_pair_key(a.scene, i, a.scene.px[r], a.scene.py[r], a.scene.pz[r],
+                                            nrx, nry, nrz, pc_norm3(nrx, nry, nrz), a.d_dist,
+                                            a.inv_d_dist, &x, &y, &z);
+        if (key != 0) {                                       /* kernel.cu:491,520 */
+            const uint32_t mask = a.table.ucap - 1;
+            uint32_t slot = slot_of(key, a.table.ushift);
+            for (uint32_t probe = 0; probe <= mask; probe++) {
+                const uint32_t k = a.table.ukeys[slot];
+                if (k == key) { hit = true; break; }
+                if (k == 0) break;
+                slot = (slot + 1) & mask;
+            }
+            if (hit) {
+                const float *rows = a.tsg + 8 * (size_t)ref_ord;
+                float vy = pc_row_dot(rows, x, y, z);         /* kernel.cu:334-336 */
+                float vz = pc_row_dot(rows + 4, x, y, z);
+                if (a.mode == 1) vy = (pm_atan2f(vz, vy) + PM_PI_F) / PM_D_ANGLE + 45.0f;
+                rec = make_uint4(key, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz),
+                                 (uint32_t)i);
+            }
+        }
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
+        base = readlane_u(base, 0);
+        if (hit) {
+            const uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+            reinterpret_cast<uint4 *>(a.hits)[(size_t)ref_local * a.hit_stride + base + rank] = rec;
+        }
+    }
+}
+
 /* One workgroup = one (scene reference point, model slice).
  * LDS: acc[1024][32] u32 = 128 KiB (one workgroup per CU, 16 waves).
  * ComputeUniqueVotes (model.cu:95-171) without the vote list: K3/K4
@@ -227,84 +336,78 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     __shared__ unsigned long long s_wave64[2][VOTE_THREADS / WAVE];
     __shared__ uint32_t s_g, s_lmax, s_base;
 
+    typedef Chunk<MODE> CH;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const int n_slices = a.table.n_slices;
-    const int ref_ord = a.first_ref + (int)(blockIdx.x / n_slices);
+    const int ref_local = (int)(blockIdx.x / n_slices);
+    const int ref_ord = a.first_ref + ref_local;
     const int slice = (int)(blockIdx.x % n_slices);
-    const int S = a.scene.n;
     const uint32_t r = a.ref_idx[ref_ord];
+    const uint32_t n_hits = a.hit_count[ref_local];
+    const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
 
     for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) acc[c] = 0;
 
-    const float prx = a.scene.px[r], pry = a.scene.py[r], prz = a.scene.pz[r];
-    const float nrx = a.scene.nx[r], nry = a.scene.ny[r], nrz = a.scene.nz[r];
-    const float nrn = pc_norm3(nrx, nry, nrz);
-    float ty[4], tz[4];
-    {
-        const float *rows = a.tsg + 8 * (size_t)ref_ord;
-        for (int q = 0; q < 4; q++) { ty[q] = rows[q]; tz[q] = rows[4 + q]; }
-    }
     const oslamk_slot *tab = a.table.slots + (size_t)slice * a.table.cap;
     const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
     const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;
     unsigned long long my_hits = 0, my_votes = 0;
     __syncthreads();
 
-    for (int base = 0; base < S; base += VOTE_THREADS) {
-        const int i = base + tid;
+    for (uint32_t base = 0; base < n_hits; base += VOTE_THREADS) {
+        const uint32_t h = base + tid;
         uint32_t start = 0, len = 0;
         float vy = 0.0f, vz = 0.0f;
-        if (i < S && (uint32_t)i != r) {
-            float x, y, z;
-            uint32_t key = cloud_pair_key(a.scene, i, prx, pry, prz, nrx, nry, nrz, nrn, a.d_dist,
-                                          a.inv_d_dist, &x, &y, &z);
-            if (key != 0) {                                   /* kernel.cu:491,520 */
-                uint32_t slot = slot_of(key, shift);
-                for (uint32_t probe = 0; probe <= mask; probe++) {
-                    const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
-                    if (sv.x == key) {
-                        start = sv.y;
-                        len = sv.z & 0x7fffffffu;
-                        my_hits += sv.z >> 31;
-                        my_votes += len;
-                        break;
-                    }
-                    if (sv.x == 0) break;
-                    slot = (slot + 1) & mask;
+        if (h < n_hits) {
+            const uint4 rec = hits[h];
+            uint32_t slot = slot_of(rec.x, shift);
+            for (uint32_t probe = 0; probe <= mask; probe++) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
+                if (sv.x == rec.x) {
+                    start = sv.y;
+                    len = sv.z;
+                    my_votes += len;
+                    break;
                 }
-                if (len) {
-                    vy = pc_row_dot(ty, x, y, z);            /* kernel.cu:334-336 */
-                    vz = pc_row_dot(tz, x, y, z);
-                    if (MODE == 1) {
-                        /* fast mode: vy carries (alpha_s + pi)/D + 45 */
-                        vy = (pm_atan2f(vz, vy) + PM_PI_F) / PM_D_ANGLE + 45.0f;
-                    }
-                }
+                if (sv.x == 0) break;
+                slot = (slot + 1) & mask;
             }
+            vy = __builtin_bit_cast(float, rec.y);
+            vz = __builtin_bit_cast(float, rec.z);
+            if (slice == 0) my_hits += 1;
         }
-        /* wave-cooperative sweep: all 64 lanes stream one bucket at a time */
+        /* wave-cooperative sweep: all 64 lanes stream one bucket at a time, in chunks of
+         * CH::U x 64 entries; the next chunk's loads (possibly of the next bucket) are in
+         * flight while the current chunk votes */
         unsigned long long todo = __ballot(len > 0);
-        while (todo) {
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint32_t st = readlane_u(start, l), ln = readlane_u(len, l);
-            const float vyl = readlane_f(vy, l), vzl = readlane_f(vz, l);
-            if (MODE == 0) {
-                for (uint32_t e = lane; e < ln; e += WAVE) {
-                    const uint4 ev = *reinterpret_cast<const uint4 *>(&a.exact[(size_t)st + e]);
-                    const unsigned bin = pc_alpha_bin_exact(__builtin_bit_cast(float, ev.y),
-                                                            __builtin_bit_cast(float, ev.z), vyl, vzl);
-                    if (bin < OSLAMK_NBIN) atomicAdd(&acc[(ev.x - m_base) * OSLAMK_NBIN + bin], 1u);
+        if (todo) {
+            int l = __ffsll((long long)todo) - 1;
+            uint32_t st = readlane_u(start, l), ln = readlane_u(len, l), off = 0;
+            float vyl = readlane_f(vy, l), vzl = readlane_f(vz, l);
+            CH nxt;
+            nxt.load(a, st, off, ln, lane);
+            for (;;) {
+                const CH cur = nxt;
+                const uint32_t coff = off, cln = ln;
+                const float cvy = vyl, cvz = vzl;
+                bool more = true;
+                off += CH::U * WAVE;
+                if (off >= ln) {
+                    todo &= todo - 1;
+                    if (todo) {
+                        l = __ffsll((long long)todo) - 1;
+                        st = readlane_u(start, l);
+                        ln = readlane_u(len, l);
+                        vyl = readlane_f(vy, l);
+                        vzl = readlane_f(vz, l);
+                        off = 0;
+                    } else {
+                        more = false;
+                    }
                 }
-            } else {
-                for (uint32_t e = lane; e < ln; e += WAVE) {
-                    const uint2 ev = *reinterpret_cast<const uint2 *>(&a.fast[(size_t)st + e]);
-                    float t = vyl - __builtin_bit_cast(float, ev.y);   /* in [15, 75] */
-                    t = t >= 30.0f ? t - 30.0f : t;
-                    t = t >= 30.0f ? t - 30.0f : t;
-                    const unsigned bin = (unsigned)(int)t;
-                    if (bin < OSLAMK_NBIN) atomicAdd(&acc[(ev.x - m_base) * OSLAMK_NBIN + bin], 1u);
-                }
+                if (more) nxt.load(a, st, off, ln, lane);
+                cur.vote(acc, m_base, coff, cln, lane, cvy, cvz);
+                if (!more) break;
             }
         }
     }
@@ -440,11 +543,11 @@ int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream)
     return (int)hipGetLastError();
 }
 
-int oslamk_table_mark_first(oslamk_table t, uint32_t *n_first, void *stream)
+int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream)
 {
     size_t total = (size_t)t.n_slices * t.cap;
-    hipLaunchKernelGGL(k_table_mark_first, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, t, n_first);
+    hipLaunchKernelGGL(k_union_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, t, n_keys, overflow);
     return (int)hipGetLastError();
 }
 
@@ -454,6 +557,14 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
 {
     hipLaunchKernelGGL(k_model_fill, dim3((c.n + 255) / 256, c.n), dim3(256), 0, (hipStream_t)stream,
                        c, d_dist, inv_d_dist, t, tmg, exact, fast);
+    return (int)hipGetLastError();
+}
+
+int oslamk_scene_hits(const oslamk_vote_args *a, void *stream)
+{
+    if (a->n_launch <= 0) return 0;
+    dim3 grid((unsigned)((a->scene.n + 255) / 256), (unsigned)a->n_launch);
+    hipLaunchKernelGGL(k_scene_hits, grid, dim3(256), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }
 

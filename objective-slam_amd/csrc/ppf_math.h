@@ -52,6 +52,12 @@ PM_HD float pm_sqrtf(float x) { return __builtin_sqrtf(x); }
 PM_HD float pm_fabsf(float x) { return PM_BITS_U2F(PM_BITS_F2U(x) & 0x7fffffffu); }
 PM_HD int pm_isnan(float x) { return (PM_BITS_F2U(x) & 0x7fffffffu) > 0x7f800000u; }
 
+/* The three functions below are written select-style: every lane runs one
+ * common operation sequence and picks its own case's operands/results, because
+ * a wave whose 64 lanes take different fdlibm branches would otherwise execute
+ * every branch (each with its own division).  Per lane the operations and
+ * their order are exactly fdlibm's for that lane's case. */
+
 /* acosf: fdlibm e_acosf.c algorithm (rational approximation on three ranges).
  * Returns the canonical NaN for |x| > 1 or NaN input. */
 PM_HD float pm_acosf(float x)
@@ -66,111 +72,75 @@ PM_HD float pm_acosf(float x)
                 pS4 = PM_BITS_U2F(0x3a4f7f04u), pS5 = PM_BITS_U2F(0x3811ef08u);
     const float qS1 = PM_BITS_U2F(0xc019d139u), qS2 = PM_BITS_U2F(0x4001572du),
                 qS3 = PM_BITS_U2F(0xbf303361u), qS4 = PM_BITS_U2F(0x3d9dc62eu);
-    uint32_t hx = PM_BITS_F2U(x);
-    uint32_t ix = hx & 0x7fffffffu;
-    int neg = (int)(hx >> 31);
-    float z, p, q, r, w, s, c, df;
-
-    if (ix == 0x3f800000u) {
-        if (!neg) return 0.0f;
-        return pi + two_pio2_lo;
-    }
-    if (ix > 0x3f800000u) return PM_BITS_U2F(PM_NAN_BITS);
-    if (ix < 0x3f000000u) {                      /* |x| < 0.5 */
-        if (ix <= 0x32800000u) return pio2_hi + pio2_lo;
-        z = x * x;
-        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        r = p / q;
-        return pio2_hi - (x - (pio2_lo - x * r));
-    }
-    if (neg) {                                   /* x < -0.5 */
-        z = (one + x) * 0.5f;
-        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        s = pm_sqrtf(z);
-        r = p / q;
-        w = r * s - pio2_lo;
-        return pi - 2.0f * (s + w);
-    }
-    z = (one - x) * 0.5f;                        /* x > 0.5 */
-    s = pm_sqrtf(z);
-    df = PM_BITS_U2F(PM_BITS_F2U(s) & 0xfffff000u);
-    c = (z - df * df) / (s + df);
-    p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    r = p / q;
-    w = r * s + c;
-    return 2.0f * (df + w);
+    const uint32_t hx = PM_BITS_F2U(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    const int neg = (int)(hx >> 31);
+    const int small = ix < 0x3f000000u;                 /* |x| < 0.5 */
+    const float ax = PM_BITS_U2F(ix);
+    /* |x| >= 0.5: z = (1 - |x|)/2  (for x < 0 fdlibm writes (one + x)*0.5: same value) */
+    const float zb = (one - ax) * 0.5f;
+    const float z = small ? x * x : zb;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float s = pm_sqrtf(zb);
+    const float df = PM_BITS_U2F(PM_BITS_F2U(s) & 0xfffff000u);
+    const float c = (zb - df * df) / (s + df);          /* x > 0.5 only */
+    const float res_small = pio2_hi - (x - (pio2_lo - x * r));
+    const float res_neg = pi - 2.0f * (s + (r * s - pio2_lo));
+    const float res_pos = 2.0f * (df + (r * s + c));
+    float res = small ? res_small : (neg ? res_neg : res_pos);
+    if (ix <= 0x32800000u) res = pio2_hi + pio2_lo;     /* |x| <= 2^-26 */
+    if (ix == 0x3f800000u) res = neg ? pi + two_pio2_lo : 0.0f;
+    if (ix > 0x3f800000u) res = PM_BITS_U2F(PM_NAN_BITS);
+    return res;
 }
 
-/* atanf: fdlibm s_atanf.c algorithm (4-way argument reduction + degree-11 odd
- * polynomial split into two chains). */
-PM_HD float pm_atanf(float x)
+/* atanf of a non-negative finite-or-inf argument, fdlibm s_atanf.c: the four
+ * argument reductions are one division num/den with per-range coefficients
+ * (num = a*x + b, den = c*x + d; a*x and c*x round exactly as fdlibm's terms). */
+PM_HD float pm_atanf_pos_(float ax)
 {
-    const float one = 1.0f;
     const float aT0 = PM_BITS_U2F(0x3eaaaaabu), aT1 = PM_BITS_U2F(0xbe4ccccdu),
                 aT2 = PM_BITS_U2F(0x3e124925u), aT3 = PM_BITS_U2F(0xbde38e38u),
                 aT4 = PM_BITS_U2F(0x3dba2e6eu), aT5 = PM_BITS_U2F(0xbd9d8795u),
                 aT6 = PM_BITS_U2F(0x3d886b35u), aT7 = PM_BITS_U2F(0xbd6ef16bu),
                 aT8 = PM_BITS_U2F(0x3d4bda59u), aT9 = PM_BITS_U2F(0xbd15a221u),
                 aT10 = PM_BITS_U2F(0x3c8569d7u);
-    uint32_t hx = PM_BITS_F2U(x);
-    uint32_t ix = hx & 0x7fffffffu;
-    int neg = (int)(hx >> 31);
-    float hi, lo, w, s1, s2, z;
-    int id;
-
-    if (ix >= 0x4c000000u) {                     /* |x| >= 2^25 */
-        if (ix > 0x7f800000u) return x + x;
-        hi = PM_BITS_U2F(0x3fc90fdau);
-        lo = PM_BITS_U2F(0x33a22168u);
-        return neg ? -hi - lo : hi + lo;
-    }
-    if (ix < 0x3ee00000u) {                      /* |x| < 0.4375 */
-        if (ix < 0x31000000u) return x;          /* |x| < 2^-29 */
-        id = -1;
-        hi = 0.0f;
-        lo = 0.0f;
-    } else {
-        x = pm_fabsf(x);
-        if (ix < 0x3f980000u) {                  /* |x| < 1.1875 */
-            if (ix < 0x3f300000u) {              /* 7/16 <= |x| < 11/16 */
-                id = 0;
-                hi = PM_BITS_U2F(0x3eed6338u);
-                lo = PM_BITS_U2F(0x31ac3769u);
-                x = (2.0f * x - one) / (2.0f + x);
-            } else {                             /* 11/16 <= |x| < 19/16 */
-                id = 1;
-                hi = PM_BITS_U2F(0x3f490fdau);
-                lo = PM_BITS_U2F(0x33222168u);
-                x = (x - one) / (x + one);
-            }
-        } else {
-            if (ix < 0x401c0000u) {              /* |x| < 2.4375 */
-                id = 2;
-                hi = PM_BITS_U2F(0x3f7b985eu);
-                lo = PM_BITS_U2F(0x33140fb4u);
-                x = (x - 1.5f) / (one + 1.5f * x);
-            } else {
-                id = 3;
-                hi = PM_BITS_U2F(0x3fc90fdau);
-                lo = PM_BITS_U2F(0x33a22168u);
-                x = -1.0f / x;
-            }
-        }
-    }
-    z = x * x;
-    w = z * z;
-    s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
-    s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return x - x * (s1 + s2);
-    z = hi - ((x * (s1 + s2) - lo) - x);
-    return neg ? -z : z;
+    const uint32_t ix = PM_BITS_F2U(ax);
+    /* range id: -1: <7/16, 0: <11/16, 1: <19/16, 2: <39/16, 3: above */
+    const int r0 = ix >= 0x3ee00000u, r1 = ix >= 0x3f300000u, r2 = ix >= 0x3f980000u,
+              r3 = ix >= 0x401c0000u;
+    const float a = r3 ? 0.0f : ((r0 && !r1) ? 2.0f : 1.0f);
+    const float b = r3 ? -1.0f : (r2 ? -1.5f : (r0 ? -1.0f : 0.0f));
+    const float c = r3 ? 1.0f : (r2 ? 1.5f : (r0 ? 1.0f : 0.0f));
+    const float d = r3 ? 0.0f : (r2 ? 1.0f : (r1 ? 1.0f : (r0 ? 2.0f : 1.0f)));
+    const float hi = PM_BITS_U2F(r3 ? 0x3fc90fdau : (r2 ? 0x3f7b985eu : (r1 ? 0x3f490fdau : (r0 ? 0x3eed6338u : 0u))));
+    const float lo = PM_BITS_U2F(r3 ? 0x33a22168u : (r2 ? 0x33140fb4u : (r1 ? 0x33222168u : (r0 ? 0x31ac3769u : 0u))));
+    const float xr = (a * ax + b) / (c * ax + d);
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    /* with hi = lo = 0 this is x - x*(s1+s2), the |x| < 7/16 form */
+    float res = hi - ((xr * (s1 + s2) - lo) - xr);
+    if (ix < 0x31000000u) res = ax;                                    /* |x| < 2^-29 */
+    if (ix >= 0x4c000000u) res = PM_BITS_U2F(0x3fc90fdau) + PM_BITS_U2F(0x33a22168u);   /* |x| >= 2^25 */
+    return res;
 }
 
-/* atan2f: fdlibm e_atan2f.c algorithm (special cases, then atanf(|y/x|) and a
- * quadrant fix-up with a split pi). */
+PM_HD float pm_atanf(float x)
+{
+    const uint32_t hx = PM_BITS_F2U(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    float r;
+    if (ix > 0x7f800000u) return x + x;
+    r = pm_atanf_pos_(PM_BITS_U2F(ix));
+    return PM_BITS_U2F(PM_BITS_F2U(r) | (hx & 0x80000000u));
+}
+
+/* atan2f: fdlibm e_atan2f.c algorithm (atanf(|y/x|), quadrant fix-up with a
+ * split pi, then the special cases as overriding selects). */
 PM_HD float pm_atan2f(float y, float x)
 {
     const float tiny = PM_BITS_U2F(0x0da24260u);
@@ -178,48 +148,34 @@ PM_HD float pm_atan2f(float y, float x)
     const float pi_o_2 = PM_BITS_U2F(0x3fc90fdbu);
     const float pi = PM_BITS_U2F(0x40490fdbu);
     const float pi_lo = PM_BITS_U2F(0xb3bbbd2eu);
-    uint32_t hx = PM_BITS_F2U(x), hy = PM_BITS_F2U(y);
-    uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
-    int xneg = (int)(hx >> 31), yneg = (int)(hy >> 31);
-    int m, k;
-    float z;
-
-    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;
-    if (hx == 0x3f800000u) return pm_atanf(y);
-    m = yneg | (xneg << 1);
-    if (iy == 0) {
-        if (m < 2) return y;
-        return (m == 2) ? pi + tiny : -pi - tiny;
+    const uint32_t hx = PM_BITS_F2U(x), hy = PM_BITS_F2U(y);
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const int xneg = (int)(hx >> 31), yneg = (int)(hy >> 31);
+    const int k = ((int32_t)iy - (int32_t)ix) >> 23;
+    const float z0 = pm_atanf_pos_(pm_fabsf(y / x));
+    float z = z0, res;
+    if (xneg && k < -60) z = 0.0f;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    {
+        const float zl = z - pi_lo;
+        const float r01 = PM_BITS_U2F(PM_BITS_F2U(z) ^ ((uint32_t)yneg << 31));
+        const float r23 = yneg ? zl - pi : pi - zl;
+        res = xneg ? r23 : r01;
     }
-    if (ix == 0) return yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (iy == 0x7f800000u) res = yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;
     if (ix == 0x7f800000u) {
         if (iy == 0x7f800000u) {
-            switch (m) {
-            case 0: return pi_o_4 + tiny;
-            case 1: return -pi_o_4 - tiny;
-            case 2: return 3.0f * pi_o_4 + tiny;
-            default: return -3.0f * pi_o_4 - tiny;
-            }
-        }
-        switch (m) {
-        case 0: return 0.0f;
-        case 1: return -0.0f;
-        case 2: return pi + tiny;
-        default: return -pi - tiny;
+            const float q1 = pi_o_4 + tiny, q3 = 3.0f * pi_o_4 + tiny;
+            res = xneg ? (yneg ? -3.0f * pi_o_4 - tiny : q3) : (yneg ? -pi_o_4 - tiny : q1);
+        } else {
+            res = xneg ? (yneg ? -pi - tiny : pi + tiny) : (yneg ? -0.0f : 0.0f);
         }
     }
-    if (iy == 0x7f800000u) return yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;
-
-    k = ((int32_t)iy - (int32_t)ix) >> 23;
-    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
-    else if (xneg && k < -60) z = 0.0f;
-    else z = pm_atanf(pm_fabsf(y / x));
-    switch (m) {
-    case 0: return z;
-    case 1: return PM_BITS_U2F(PM_BITS_F2U(z) ^ 0x80000000u);
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
-    }
+    if (ix == 0) res = yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (iy == 0) res = xneg ? (yneg ? -pi - tiny : pi + tiny) : y;
+    if (hx == 0x3f800000u) res = PM_BITS_U2F(PM_BITS_F2U(z0) | (hy & 0x80000000u));   /* atanf(y) */
+    if (ix > 0x7f800000u || iy > 0x7f800000u) res = x + y;
+    return res;
 }
 
 /* Exact x - fmodf(x, step) for x >= 0 (or NaN), step > 0:
