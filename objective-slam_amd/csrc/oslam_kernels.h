@@ -25,18 +25,24 @@ typedef struct oslamk_slot {
     uint32_t cur;              /* fill cursor (== len after the build) */
 } oslamk_slot;
 
-/* Model pair entry, exact mode: what one vote needs of the model side. */
-typedef struct oslamk_entry_exact {
-    uint32_t m_r;
-    float uy, uz;              /* (T_m_g * m_i).y/.z, kernel.cu:330-332 */
-    uint32_t m_i;
-} oslamk_entry_exact;
+/* Model pair entries, bucketed by (slice, key).  Exact mode streams 10 bytes per vote:
+ * uv[e] = (T_m_g * m_i).y/.z (kernel.cu:330-332) and mr[e] = m_r - slice*OSLAMK_SLICE. */
+typedef struct oslamk_uv {
+    float uy, uz;
+} oslamk_uv;
 
-/* Model pair entry, fast mode: 8 bytes. */
+/* Fast mode: 8 bytes per vote. */
 typedef struct oslamk_entry_fast {
     uint32_t m_r;
     float am;                  /* (alpha_m + pi) / D_ANGLE0 */
 } oslamk_entry_fast;
+
+typedef struct oslamk_entries {
+    oslamk_uv *uv;             /* exact mode (NULL in fast mode) */
+    uint16_t *mr;              /* slice-local model reference index */
+    uint16_t *mi;              /* model second point (parity tap only) */
+    oslamk_entry_fast *fast;   /* fast mode (NULL in exact mode) */
+} oslamk_entries;
 
 /* A cloud in HBM: structure of arrays. */
 typedef struct oslamk_cloud {
@@ -81,11 +87,9 @@ int oslamk_model_count(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_ta
 int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
 /* fill t.ukeys with every distinct key; *n_keys = number of distinct keys */
 int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream);
-/* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed).
- * fast may be NULL. */
+/* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed). */
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
-                      const float *tmg, oslamk_entry_exact *exact, oslamk_entry_fast *fast,
-                      void *stream);
+                      const float *tmg, oslamk_entries ent, void *stream);
 
 typedef struct oslamk_hit {
     uint32_t key, vy_bits, vz_bits, index;
@@ -98,8 +102,7 @@ typedef struct oslamk_vote_args {
     int n_ref;
     float d_dist, inv_d_dist;
     oslamk_table table;
-    const oslamk_entry_exact *exact;
-    const oslamk_entry_fast *fast;
+    oslamk_entries ent;
     float thresh;              /* vote_count_threshold */
     uint32_t fixed_gmax;       /* != 0: emit cells with count > thresh*fixed_gmax only */
     oslamk_counters *counters;

@@ -24,6 +24,9 @@
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
 
+/* thresholds of pc_alpha_bin_table(); every vote workgroup copies them into LDS */
+__device__ const uint32_t k_alpha_thr[32] = {PC_ALPHA_THR_FLAT};
+
 __device__ __forceinline__ uint32_t slot_of(uint32_t key, uint32_t shift)
 {
     return (key * 2654435761u) >> shift;
@@ -142,7 +145,7 @@ __global__ void k_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overfl
 
 /* pass 2: same pairs, written into their buckets */
 __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
-                             const float *tmg, oslamk_entry_exact *exact, oslamk_entry_fast *fast)
+                             const float *tmg, oslamk_entries ent)
 {
     int m_r = blockIdx.y;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,17 +166,19 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
     size_t e = (size_t)tab[slot].start + pos;
     const float *rows = tmg + 8 * (size_t)m_r;
     float uy = pc_row_dot(rows, x, y, z), uz = pc_row_dot(rows + 4, x, y, z);
-    oslamk_entry_exact en;
-    en.m_r = (uint32_t)m_r;
-    en.uy = uy;
-    en.uz = uz;
-    en.m_i = (uint32_t)i;
-    exact[e] = en;
-    if (fast) {
+    ent.mr[e] = (uint16_t)(m_r - slice * OSLAMK_SLICE);
+    ent.mi[e] = (uint16_t)i;
+    if (ent.uv) {
+        oslamk_uv en;
+        en.uy = uy;
+        en.uz = uz;
+        ent.uv[e] = en;
+    }
+    if (ent.fast) {
         oslamk_entry_fast ef;
         ef.m_r = (uint32_t)m_r;
         ef.am = (pm_atan2f(uz, uy) + PM_PI_F) / PM_D_ANGLE;
-        fast[e] = ef;
+        ent.fast[e] = ef;
     }
 }
 
@@ -213,28 +218,31 @@ template <int MODE>
 struct Chunk;
 
 template <>
-struct Chunk<0> {                      /* exact mode: 16-byte entries */
+struct Chunk<0> {                      /* exact mode: 8-byte (uy,uz) + 2-byte local m_r */
     static constexpr int U = 4;
-    uint4 v[U];
+    float2 v[U];
+    uint32_t mr[U];
     __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
                                          uint32_t ln, int lane)
     {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t idx = off + u * WAVE + lane;
-            if (idx < ln) v[u] = *reinterpret_cast<const uint4 *>(&a.exact[(size_t)st + idx]);
+            if (idx < ln) {
+                v[u] = *reinterpret_cast<const float2 *>(&a.ent.uv[(size_t)st + idx]);
+                mr[u] = a.ent.mr[(size_t)st + idx];
+            }
         }
     }
-    __device__ __forceinline__ void vote(uint32_t *acc, uint32_t m_base, uint32_t off, uint32_t ln,
-                                         int lane, float vy, float vz) const
+    __device__ __forceinline__ void vote(uint32_t *acc, const uint32_t *tbl, uint32_t,
+                                         uint32_t off, uint32_t ln, int lane, float vy, float vz) const
     {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t idx = off + u * WAVE + lane;
             if (idx < ln) {
-                const unsigned bin = pc_alpha_bin_exact(__builtin_bit_cast(float, v[u].y),
-                                                        __builtin_bit_cast(float, v[u].z), vy, vz);
-                if (bin < OSLAMK_NBIN) atomicAdd(&acc[(v[u].x - m_base) * OSLAMK_NBIN + bin], 1u);
+                const unsigned bin = pc_alpha_bin_table(v[u].x, v[u].y, vy, vz, tbl);
+                if (bin < OSLAMK_NBIN) atomicAdd(&acc[mr[u] * OSLAMK_NBIN + bin], 1u);
             }
         }
     }
@@ -250,11 +258,11 @@ struct Chunk<1> {                      /* fast mode: 8-byte entries */
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t idx = off + u * WAVE + lane;
-            if (idx < ln) v[u] = *reinterpret_cast<const uint2 *>(&a.fast[(size_t)st + idx]);
+            if (idx < ln) v[u] = *reinterpret_cast<const uint2 *>(&a.ent.fast[(size_t)st + idx]);
         }
     }
-    __device__ __forceinline__ void vote(uint32_t *acc, uint32_t m_base, uint32_t off, uint32_t ln,
-                                         int lane, float cs, float) const
+    __device__ __forceinline__ void vote(uint32_t *acc, const uint32_t *, uint32_t m_base,
+                                         uint32_t off, uint32_t ln, int lane, float cs, float) const
     {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
     __shared__ unsigned long long s_wave64[2][VOTE_THREADS / WAVE];
     __shared__ uint32_t s_g, s_lmax, s_base;
+    __shared__ uint32_t s_tbl[32];
 
     typedef Chunk<MODE> CH;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
 
     for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) acc[c] = 0;
+    if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
 
     const oslamk_slot *tab = a.table.slots + (size_t)slice * a.table.cap;
     const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                     }
                 }
                 if (more) nxt.load(a, st, off, ln, lane);
-                cur.vote(acc, m_base, coff, cln, lane, cvy, cvz);
+                cur.vote(acc, s_tbl, m_base, coff, cln, lane, cvy, cvz);
                 if (!more) break;
             }
         }
@@ -507,13 +517,16 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 __global__ void k_selftest(const float *x, const float *y, const float *x2, size_t n, float *out_acos,
                            float *out_atan2, uint32_t *out_quant, uint32_t *out_bin)
 {
+    __shared__ uint32_t s_tbl[32];
+    if (threadIdx.x < 32) s_tbl[threadIdx.x] = k_alpha_thr[threadIdx.x];
+    __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out_acos[i] = pm_acosf(x[i]);
     out_atan2[i] = pm_atan2f(y[i], x2[i]);
     out_quant[i] = pc_quant_bits(pm_fabsf(y[i]) * 7.0f, 0.0371f + pm_fabsf(x[i]) * 0.01f,
                                  1.0f / (0.0371f + pm_fabsf(x[i]) * 0.01f));
-    out_bin[i] = pc_alpha_bin_exact(y[i], x2[i], x[i], y[i] - x2[i]);
+    out_bin[i] = pc_alpha_bin_table(y[i], x2[i], x[i], y[i] - x2[i], s_tbl);
 }
 
 /* --------------------------------------------------------------------------
@@ -552,11 +565,10 @@ int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, voi
 }
 
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
-                      const float *tmg, oslamk_entry_exact *exact, oslamk_entry_fast *fast,
-                      void *stream)
+                      const float *tmg, oslamk_entries ent, void *stream)
 {
     hipLaunchKernelGGL(k_model_fill, dim3((c.n + 255) / 256, c.n), dim3(256), 0, (hipStream_t)stream,
-                       c, d_dist, inv_d_dist, t, tmg, exact, fast);
+                       c, d_dist, inv_d_dist, t, tmg, ent);
     return (int)hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 #ifndef OSLAM_PPF_CORE_H
 #define OSLAM_PPF_CORE_H
 
+#include "ppf_alpha_table.h"
 #include "ppf_math.h"
 
 #include <math.h>
@@ -78,6 +79,36 @@ PM_HD unsigned pc_alpha_bin_exact(float uy, float uz, float vy, float vz)
     (void)pm_quant_down_pos(alpha, PM_D_ANGLE, 1.0f / PM_D_ANGLE, &k);
     /* lrintf(RN(k*D)/D) == k for k <= 31: |RN(k*D)/D - k| <= 31*2^-23 */
     return ((unsigned)k > 31u) ? 255u : (unsigned)k;
+}
+
+/* The same bin without evaluating atan2f: in atan2f's main path the result is a
+ * function of q = fl(|cross/dot|) and the two signs only, and the bin is a monotone
+ * step function of q whose steps (ppf_alpha_table.h) were found by evaluating the
+ * exact formula on every float q.  One division, four table reads.  `tbl` is the
+ * table PC_ALPHA_THR (32 words; the kernels keep a copy in LDS, one word per bank).
+ * Inputs outside the main path (zero, infinite, NaN or 2^60 apart) take the full
+ * formula. */
+PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const uint32_t *tbl)
+{
+    const float cx = uy * vz - uz * vy;
+    const float dt = 0.0f * 0.0f + uy * vy + uz * vz;
+    const uint32_t hy = PM_BITS_F2U(cx), hx = PM_BITS_F2U(dt);
+    const uint32_t iy = hy & 0x7fffffffu, ix = hx & 0x7fffffffu;
+    const int k = ((int32_t)iy - (int32_t)ix) >> 23;
+    /* iy, ix in [1, 0x7f7fffff] and |k| <= 60 */
+    if ((iy - 1u) < 0x7f7fffffu && (ix - 1u) < 0x7f7fffffu && (unsigned)(k + 60) <= 120u) {
+        const uint32_t qb = PM_BITS_F2U(PM_BITS_U2F(iy) / PM_BITS_U2F(ix));
+        const unsigned m = (hy >> 31) | ((hx >> 31) << 1);
+        const uint32_t *row = tbl + 8 * m;
+        unsigned pos = (row[4] <= qb) ? 4u : 0u;
+        const unsigned tiny = row[0] <= qb;
+        pos += (row[pos + 2] <= qb) ? 2u : 0u;
+        pos += (row[pos + 1] <= qb) ? 1u : 0u;
+        pos += tiny;
+        /* PC_ALPHA_BASE = {15, 15, 30, 0}; + for quadrants 0 and 3, - for 1 and 2 */
+        return (m == 0u) ? 15u + pos : (m == 1u) ? 15u - pos : (m == 2u) ? 30u - pos : pos;
+    }
+    return pc_alpha_bin_exact(uy, uz, vy, vz);
 }
 
 #endif /* OSLAM_PPF_CORE_H */

@@ -6,6 +6,7 @@
  *   math_exhaustive atanf  STRIDE   all floats i*STRIDE: pm_atanf vs atanf
  *   math_exhaustive atan2f N        N pseudo-random + structured (y,x) pairs
  *   math_exhaustive quant  N        pm_quant_down_pos vs x - fmodf(x, step)
+ *   math_exhaustive alphabin N      pc_alpha_bin_table vs the libm formula of kernel.cu:338-342
  *
  * Prints "mismatches=K checked=N" and exits non-zero when K != 0.
  * NaN results compare equal when both are NaN (payload is canonicalised by the
@@ -17,7 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "ppf_math.h"
+#include "ppf_core.h"
 
 static uint64_t splitmix(uint64_t *s)
 {
@@ -119,6 +120,40 @@ int main(int argc, char **argv)
             if (!same(a, b)) {
                 bad++;
                 if (bad < 5) fprintf(stderr, "quant(%a,%a): pm=%a libm=%a\n", x, step, a, b);
+            }
+        }
+    } else if (!strcmp(mode, "alphabin")) {
+#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+        for (uint64_t i = 0; i < arg; i++) {
+            uint64_t s = i * 0xd1342543de82ef95ull + 99;
+            uint64_t r = splitmix(&s), r2 = splitmix(&s);
+            float uy, uz, vy, vz;
+            if ((i & 7) == 7) {          /* arbitrary bit patterns */
+                uy = PM_BITS_U2F((uint32_t)r); uz = PM_BITS_U2F((uint32_t)(r >> 32));
+                vy = PM_BITS_U2F((uint32_t)r2); vz = PM_BITS_U2F((uint32_t)(r2 >> 32));
+            } else {
+                uy = (float)((double)(int32_t)(uint32_t)r / 2147483648.0 * 3.0);
+                uz = (float)((double)(int32_t)(uint32_t)(r >> 32) / 2147483648.0 * 3.0);
+                vy = (float)((double)(int32_t)(uint32_t)r2 / 2147483648.0 * 3.0);
+                vz = (float)((double)(int32_t)(uint32_t)(r2 >> 32) / 2147483648.0 * 3.0);
+                if ((i & 7) == 1) { vy = uy; vz = uz; }              /* alpha = 0 */
+                if ((i & 7) == 2) { vy = -uy; vz = -uz; }            /* alpha = +-pi */
+                if ((i & 7) == 3) { vy = -uz; vz = uy; }             /* alpha = pi/2 */
+                if ((i & 7) == 4) {                                  /* on a bin edge: alpha = 12 deg * j */
+                    double a = 0.20943951023931953 * (double)((r2 >> 7) % 30), c = cos(a), sn = sin(a);
+                    vy = (float)(uy * c - uz * sn); vz = (float)(uy * sn + uz * c);
+                }
+            }
+            unsigned a = pc_alpha_bin_table(uy, uz, vy, vz, &PC_ALPHA_THR[0][0]);
+            /* the reference's own sequence with libm (kernel.cu:338-342) */
+            float cx = uy * vz - uz * vy, dt = 0.0f * 0.0f + uy * vy + uz * vz;
+            float al = atan2f(cx, dt) + PM_PI_F;
+            float aq = al - fmodf(al, PM_D_ANGLE);
+            unsigned b = isnan(aq) ? 255u : (unsigned)lrintf(aq / PM_D_ANGLE);
+            checked++;
+            if (a != b) {
+                bad++;
+                if (bad < 5) fprintf(stderr, "alphabin(%a,%a,%a,%a): table=%u libm=%u\n", uy, uz, vy, vz, a, b);
             }
         }
     } else {
