@@ -21,6 +21,12 @@
 #include "ppf_core.h"
 
 #define WAVE 64
+#ifndef EXACT_U
+#define EXACT_U 4
+#endif
+#ifndef FAST_U
+#define FAST_U 4
+#endif
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
 
@@ -219,7 +225,8 @@ struct Chunk;
 
 template <>
 struct Chunk<0> {                      /* exact mode: 8-byte (uy,uz) + 2-byte local m_r */
-    static constexpr int U = 4;
+    static constexpr int U = EXACT_U;
+    static_assert(EXACT_U <= 4, "vote() dispatches on at most 4 groups");
     float2 v[U];
     uint32_t mr[U];
     __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
@@ -234,14 +241,56 @@ struct Chunk<0> {                      /* exact mode: 8-byte (uy,uz) + 2-byte lo
             }
         }
     }
-    __device__ __forceinline__ void vote(uint32_t *acc, const uint32_t *tbl, uint32_t,
+    /* The U votes of a lane are evaluated side by side (stage by stage, no branches), so
+     * their divisions and the dependent LDS table reads of pc_alpha_bin_table overlap. */
+    __device__ __forceinline__ void vote(uint32_t *acc, const uint32_t *tbl, uint32_t m_base,
                                          uint32_t off, uint32_t ln, int lane, float vy, float vz) const
     {
+        /* only the 64-entry groups that hold entries (wave-uniform count) */
+        const uint32_t groups = (ln - off + WAVE - 1) / WAVE;
+        if (groups >= 4 || U < 4) vote_n<(U < 4 ? U : 4)>(acc, tbl, m_base, off, ln, lane, vy, vz);
+        else if (groups == 3) vote_n<(U < 3 ? U : 3)>(acc, tbl, m_base, off, ln, lane, vy, vz);
+        else if (groups == 2) vote_n<(U < 2 ? U : 2)>(acc, tbl, m_base, off, ln, lane, vy, vz);
+        else vote_n<1>(acc, tbl, m_base, off, ln, lane, vy, vz);
+    }
+    template <int N>
+    __device__ __forceinline__ void vote_n(uint32_t *acc, const uint32_t *tbl, uint32_t,
+                                           uint32_t off, uint32_t ln, int lane, float vy, float vz) const
+    {
+        uint32_t qb[N], row[N], pos[N], tiny[N];
+        bool ok[N], live[N], pos_dir[N];
+        uint32_t base[N];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t idx = off + u * WAVE + lane;
-            if (idx < ln) {
-                const unsigned bin = pc_alpha_bin_table(v[u].x, v[u].y, vy, vz, tbl);
+        for (int u = 0; u < N; u++) {
+            const float uy = v[u].x, uz = v[u].y;
+            const float cx = uy * vz - uz * vy;                    /* kernel.cu:84 */
+            const float dt = 0.0f * 0.0f + uy * vy + uz * vz;      /* kernel.cu:52, u.x = v.x = 0 */
+            const uint32_t hy = __builtin_bit_cast(uint32_t, cx), hx = __builtin_bit_cast(uint32_t, dt);
+            const uint32_t iy = hy & 0x7fffffffu, ix = hx & 0x7fffffffu;
+            const int k = ((int32_t)iy - (int32_t)ix) >> 23;
+            const uint32_t m = (hy >> 31) | ((hx >> 31) << 1);
+            live[u] = off + u * WAVE + lane < ln;
+            ok[u] = (iy - 1u) < 0x7f7fffffu && (ix - 1u) < 0x7f7fffffu && (unsigned)(k + 60) <= 120u;
+            qb[u] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, iy) / __builtin_bit_cast(float, ix));
+            row[u] = 8u * m;
+            pos_dir[u] = (m == 0u) || (m == 3u);
+            base[u] = (m == 2u) ? 30u : ((m == 3u) ? 0u : 15u);   /* PC_ALPHA_BASE */
+        }
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            tiny[u] = tbl[row[u]] <= qb[u];
+            pos[u] = (tbl[row[u] + 4] <= qb[u]) ? 4u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < N; u++) pos[u] += (tbl[row[u] + pos[u] + 2] <= qb[u]) ? 2u : 0u;
+#pragma unroll
+        for (int u = 0; u < N; u++) pos[u] += (tbl[row[u] + pos[u] + 1] <= qb[u]) ? 1u : 0u;
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            const uint32_t cnt = pos[u] + tiny[u];
+            unsigned bin = pos_dir[u] ? base[u] + cnt : base[u] - cnt;
+            if (live[u]) {
+                if (!ok[u]) bin = pc_alpha_bin_exact(v[u].x, v[u].y, vy, vz);   /* zero/inf/NaN: full formula */
                 if (bin < OSLAMK_NBIN) atomicAdd(&acc[mr[u] * OSLAMK_NBIN + bin], 1u);
             }
         }
@@ -250,7 +299,7 @@ struct Chunk<0> {                      /* exact mode: 8-byte (uy,uz) + 2-byte lo
 
 template <>
 struct Chunk<1> {                      /* fast mode: 8-byte entries */
-    static constexpr int U = 8;
+    static constexpr int U = FAST_U;
     uint2 v[U];
     __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
                                          uint32_t ln, int lane)

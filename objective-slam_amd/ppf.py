@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboslam_hip.so")
+LIB_PATH = os.environ.get("OSLAM_LIB", os.path.join(_HERE, "liboslam_hip.so"))   # OSLAM_LIB: A/B builds
 _LIB = None
 
 OSLAM_OK, OSLAM_E_INVALID, OSLAM_E_DEVICE, OSLAM_E_NOMEM, OSLAM_E_NO_VOTES, OSLAM_E_LIMIT = range(6)
