@@ -33,8 +33,10 @@ extern "C" {
 #define OSLAM_E_LIMIT 5       /* cloud exceeds an encoding limit (see oslam_model_create) */
 
 /* Per-vote arithmetic of the alpha angle (reference src/cuda/kernel.cu:302-342). */
-#define OSLAM_VOTE_EXACT 0    /* same float operations as the reference: identical accumulator */
-#define OSLAM_VOTE_FAST 1     /* alpha = alpha_scene - alpha_model (Drost): 8-byte model entries */
+#define OSLAM_VOTE_EXACT 0    /* accumulator identical to the reference's: alpha from quantised angles,
+                               * re-evaluated with the reference's float sequence near bin edges */
+#define OSLAM_VOTE_FAST 1     /* quantised angles only (Drost's alpha_scene - alpha_model): bins can
+                               * differ from the reference's within 2e-5 bin of an edge */
 
 /* Flags of the reference's CLI that reach the path (src/alignment.cpp:119-172)
  * plus this build's extensions.  oslam_params_default() fills the reference's

@@ -217,10 +217,9 @@ void oslam_model_destroy(oslam_model *m)
     (void)hipSetDevice(m->dev);
     cloud_free(&m->c);
     if (m->table.slots) (void)hipFree(m->table.slots);
+    if (m->ent.e4) (void)hipFree(m->ent.e4);
     if (m->ent.uv) (void)hipFree(m->ent.uv);
-    if (m->ent.mr) (void)hipFree(m->ent.mr);
     if (m->ent.mi) (void)hipFree(m->ent.mi);
-    if (m->ent.fast) (void)hipFree(m->ent.fast);
     if (m->table.ukeys) (void)hipFree(m->table.ukeys);
     if (m->d_hits) (void)hipFree(m->d_hits);
     if (m->d_hit_count) (void)hipFree(m->d_hit_count);
@@ -315,11 +314,9 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     oslam_T_g_rows(m->c.h_xyz, m->c.h_nrm, NULL, n, h_tmg);
     HIPCHK(hipMalloc((void **)&d_tmg, sizeof(float) * 8 * n));
     HIPCHK(hipMemcpy(d_tmg, h_tmg, sizeof(float) * 8 * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void **)&m->ent.mr, sizeof(uint16_t) * n_pairs));
+    HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * n_pairs));
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
-    if (m->params.vote_mode == OSLAM_VOTE_FAST)
-        HIPCHK(hipMalloc((void **)&m->ent.fast, sizeof(oslamk_entry_fast) * n_pairs));
-    else
+    if (m->params.vote_mode != OSLAM_VOTE_FAST)
         HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
     KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->ent, g_stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
@@ -471,7 +468,7 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.out_cap = m->out_cap;
     a.acc_dump = NULL;
     a.dump_ref = -1;
-    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST && m->ent.fast) ? 1 : 0;
+    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
     a.hits = m->d_hits;
     a.hit_count = m->d_hit_count;
     a.hit_stride = (size_t)s->c.n;
@@ -710,7 +707,8 @@ int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t
     int rc = OSLAM_OK;
     size_t total = 0, written = 0, n_slots;
     int s;
-    uint16_t *tmp = NULL;
+    uint32_t *tmp = NULL;
+    uint16_t *tmi = NULL;
     if (!m || !count_out) return fail(OSLAM_E_INVALID, "NULL argument");
     *count_out = 0;
     if (key == 0) return OSLAM_OK;             /* never matched: kernel.cu:491 */
@@ -727,12 +725,13 @@ int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t
         for (probe = 0; probe <= mask; probe++) {
             if (tab[slot].key == key) {
                 uint32_t len = tab[slot].len, e;
-                tmp = (uint16_t *)realloc(tmp, sizeof(uint16_t) * 2 * (len ? len : 1));
-                HIPCHK(hipMemcpy(tmp, m->ent.mr + tab[slot].start, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(tmp + len, m->ent.mi + tab[slot].start, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
+                tmp = (uint32_t *)realloc(tmp, sizeof(uint32_t) * (len ? len : 1));
+                tmi = (uint16_t *)realloc(tmi, sizeof(uint16_t) * (len ? len : 1));
+                HIPCHK(hipMemcpy(tmp, m->ent.e4 + tab[slot].start, sizeof(uint32_t) * len, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(tmi, m->ent.mi + tab[slot].start, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
                 for (e = 0; e < len; e++, total++)
                     if (pairs_out && written < cap)
-                        pairs_out[written++] = ((uint32_t)s * OSLAMK_SLICE + tmp[e]) * (uint32_t)m->c.n + tmp[len + e];
+                        pairs_out[written++] = ((uint32_t)s * OSLAMK_SLICE + (tmp[e] >> 22)) * (uint32_t)m->c.n + tmi[e];
                 break;
             }
             if (tab[slot].key == 0) break;
@@ -743,6 +742,7 @@ int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t
     *count_out = total;
 done:
     free(tmp);
+    free(tmi);
     return rc;
 }
 
@@ -784,7 +784,7 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
     a.dump_ref = 0;
     a.first_ref = 0;
     a.n_launch = 1;
-    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST && m->ent.fast) ? 1 : 0;
+    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
     {
         int batch = 1;
         rc = ensure_hit_scratch(m, s, &batch);

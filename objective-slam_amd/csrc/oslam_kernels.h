@@ -25,23 +25,21 @@ typedef struct oslamk_slot {
     uint32_t cur;              /* fill cursor (== len after the build) */
 } oslamk_slot;
 
-/* Model pair entries, bucketed by (slice, key).  Exact mode streams 10 bytes per vote:
- * uv[e] = (T_m_g * m_i).y/.z (kernel.cu:330-332) and mr[e] = m_r - slice*OSLAMK_SLICE. */
+/* Model pair entries, bucketed by (slice, key); every bucket starts on a multiple of 4
+ * entries so that a lane can fetch 4 of them with one 16-byte load.
+ *   e4[e] = (m_r - slice*OSLAMK_SLICE) << 22 | theta_u   the 4 bytes a vote streams
+ *           (theta_u = pc_angle_q17 of (T_m_g * m_i).y/.z, kernel.cu:330-332)
+ *   uv[e] = (T_m_g * m_i).y/.z as floats: read only by the rare votes that are
+ *           re-evaluated with the reference's own arithmetic (exact mode)
+ *   mi[e] = m_i (parity tap only) */
 typedef struct oslamk_uv {
     float uy, uz;
 } oslamk_uv;
 
-/* Fast mode: 8 bytes per vote. */
-typedef struct oslamk_entry_fast {
-    uint32_t m_r;
-    float am;                  /* (alpha_m + pi) / D_ANGLE0 */
-} oslamk_entry_fast;
-
 typedef struct oslamk_entries {
-    oslamk_uv *uv;             /* exact mode (NULL in fast mode) */
-    uint16_t *mr;              /* slice-local model reference index */
-    uint16_t *mi;              /* model second point (parity tap only) */
-    oslamk_entry_fast *fast;   /* fast mode (NULL in exact mode) */
+    uint32_t *e4;
+    oslamk_uv *uv;             /* NULL in fast mode */
+    uint16_t *mi;
 } oslamk_entries;
 
 /* A cloud in HBM: structure of arrays. */
@@ -83,7 +81,8 @@ int oslamk_row_keys(oslamk_cloud c, int ref, float d_dist, float inv_d_dist, uin
  * slice table filled up */
 int oslamk_model_count(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
                        uint32_t *n_unique, uint32_t *overflow, void *stream);
-/* exclusive scan of slot.len over all slots -> slot.start; total written to *total_out */
+/* exclusive scan of slot.len (each rounded up to a multiple of 4) over all slots -> slot.start;
+ * padded total written to *total_out */
 int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
 /* fill t.ukeys with every distinct key; *n_keys = number of distinct keys */
 int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream);
@@ -92,7 +91,7 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
                       const float *tmg, oslamk_entries ent, void *stream);
 
 typedef struct oslamk_hit {
-    uint32_t key, vy_bits, vz_bits, index;
+    uint32_t key, vy_bits, vz_bits, theta_q17;
 } oslamk_hit;
 
 typedef struct oslamk_vote_args {
@@ -112,9 +111,9 @@ typedef struct oslamk_vote_args {
     int dump_ref;
     int first_ref;             /* launch covers reference ordinals first_ref .. first_ref+n_launch-1 */
     int n_launch;
-    int mode;                  /* 0 exact, 1 fast */
+    int mode;                  /* 0 exact (near-edge votes re-evaluated), 1 fast (never) */
     /* per-reference hit lists of this batch (written by oslamk_scene_hits, read by oslamk_vote):
-     * hits[ref_local * hit_stride + k] = {key, vy bits, vz bits, scene index}, k < hit_count[ref_local] */
+     * hits[ref_local * hit_stride + k] = {key, vy bits, vz bits, theta_v}, k < hit_count[ref_local] */
     oslamk_hit *hits;
     uint32_t *hit_count;
     size_t hit_stride;

@@ -21,11 +21,8 @@
 #include "ppf_core.h"
 
 #define WAVE 64
-#ifndef EXACT_U
-#define EXACT_U 4
-#endif
-#ifndef FAST_U
-#define FAST_U 4
+#ifndef VOTE_U
+#define VOTE_U 2          /* 16-byte loads per lane per chunk: 256*VOTE_U entries per wave */
 #endif
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
@@ -110,7 +107,7 @@ __global__ __launch_bounds__(1024) void k_table_scan(oslamk_table t, uint32_t *t
     size_t chunk = (total + 1023) / 1024;
     size_t b = (size_t)threadIdx.x * chunk, e = b + chunk < total ? b + chunk : total;
     uint32_t s = 0;
-    for (size_t i = b; i < e; i++) s += t.slots[i].len;
+    for (size_t i = b; i < e; i++) s += (t.slots[i].len + 3u) & ~3u;
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_table_scan(oslamk_table t, uint32_t *t
     uint32_t run = part[threadIdx.x];
     for (size_t i = b; i < e; i++) {
         t.slots[i].start = run;
-        run += t.slots[i].len;
+        run += (t.slots[i].len + 3u) & ~3u;
     }
 }
 
@@ -172,19 +169,13 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
     size_t e = (size_t)tab[slot].start + pos;
     const float *rows = tmg + 8 * (size_t)m_r;
     float uy = pc_row_dot(rows, x, y, z), uz = pc_row_dot(rows + 4, x, y, z);
-    ent.mr[e] = (uint16_t)(m_r - slice * OSLAMK_SLICE);
+    ent.e4[e] = ((uint32_t)(m_r - slice * OSLAMK_SLICE) << 22) | pc_angle_q17(uy, uz);
     ent.mi[e] = (uint16_t)i;
     if (ent.uv) {
         oslamk_uv en;
         en.uy = uy;
         en.uz = uz;
         ent.uv[e] = en;
-    }
-    if (ent.fast) {
-        oslamk_entry_fast ef;
-        ef.m_r = (uint32_t)m_r;
-        ef.am = (pm_atan2f(uz, uy) + PM_PI_F) / PM_D_ANGLE;
-        ent.fast[e] = ef;
     }
 }
 
@@ -219,109 +210,44 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
-/* A chunk of U x 64 model-pair entries held in registers by one wave. */
+/* A chunk of VOTE_U x 256 model-pair entries held in registers by one wave: lane l holds
+ * entries 4*(u*64 + l) .. +3 of the chunk (one 16-byte load each).
+ * A vote: theta_v - theta_u in units of 2^-17 bin gives bin and position in the bin; only
+ * positions within 2^-10 bin of an edge (0.2 % of votes) are re-evaluated with the reference's
+ * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's. */
 template <int MODE>
-struct Chunk;
-
-template <>
-struct Chunk<0> {                      /* exact mode: 8-byte (uy,uz) + 2-byte local m_r */
-    static constexpr int U = EXACT_U;
-    static_assert(EXACT_U <= 4, "vote() dispatches on at most 4 groups");
-    float2 v[U];
-    uint32_t mr[U];
+struct Chunk {
+    static constexpr int U = VOTE_U;
+    uint4 v[U];
     __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
                                          uint32_t ln, int lane)
     {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t idx = off + u * WAVE + lane;
-            if (idx < ln) {
-                v[u] = *reinterpret_cast<const float2 *>(&a.ent.uv[(size_t)st + idx]);
-                mr[u] = a.ent.mr[(size_t)st + idx];
-            }
+            const uint32_t e = off + 4u * (u * WAVE + lane);
+            if (e < ln) v[u] = *reinterpret_cast<const uint4 *>(&a.ent.e4[(size_t)st + e]);
         }
     }
-    /* The U votes of a lane are evaluated side by side (stage by stage, no branches), so
-     * their divisions and the dependent LDS table reads of pc_alpha_bin_table overlap. */
-    __device__ __forceinline__ void vote(uint32_t *acc, const uint32_t *tbl, uint32_t m_base,
-                                         uint32_t off, uint32_t ln, int lane, float vy, float vz) const
-    {
-        /* only the 64-entry groups that hold entries (wave-uniform count) */
-        const uint32_t groups = (ln - off + WAVE - 1) / WAVE;
-        if (groups >= 4 || U < 4) vote_n<(U < 4 ? U : 4)>(acc, tbl, m_base, off, ln, lane, vy, vz);
-        else if (groups == 3) vote_n<(U < 3 ? U : 3)>(acc, tbl, m_base, off, ln, lane, vy, vz);
-        else if (groups == 2) vote_n<(U < 2 ? U : 2)>(acc, tbl, m_base, off, ln, lane, vy, vz);
-        else vote_n<1>(acc, tbl, m_base, off, ln, lane, vy, vz);
-    }
-    template <int N>
-    __device__ __forceinline__ void vote_n(uint32_t *acc, const uint32_t *tbl, uint32_t,
-                                           uint32_t off, uint32_t ln, int lane, float vy, float vz) const
-    {
-        uint32_t qb[N], row[N], pos[N], tiny[N];
-        bool ok[N], live[N], pos_dir[N];
-        uint32_t base[N];
-#pragma unroll
-        for (int u = 0; u < N; u++) {
-            const float uy = v[u].x, uz = v[u].y;
-            const float cx = uy * vz - uz * vy;                    /* kernel.cu:84 */
-            const float dt = 0.0f * 0.0f + uy * vy + uz * vz;      /* kernel.cu:52, u.x = v.x = 0 */
-            const uint32_t hy = __builtin_bit_cast(uint32_t, cx), hx = __builtin_bit_cast(uint32_t, dt);
-            const uint32_t iy = hy & 0x7fffffffu, ix = hx & 0x7fffffffu;
-            const int k = ((int32_t)iy - (int32_t)ix) >> 23;
-            const uint32_t m = (hy >> 31) | ((hx >> 31) << 1);
-            live[u] = off + u * WAVE + lane < ln;
-            ok[u] = (iy - 1u) < 0x7f7fffffu && (ix - 1u) < 0x7f7fffffu && (unsigned)(k + 60) <= 120u;
-            qb[u] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, iy) / __builtin_bit_cast(float, ix));
-            row[u] = 8u * m;
-            pos_dir[u] = (m == 0u) || (m == 3u);
-            base[u] = (m == 2u) ? 30u : ((m == 3u) ? 0u : 15u);   /* PC_ALPHA_BASE */
-        }
-#pragma unroll
-        for (int u = 0; u < N; u++) {
-            tiny[u] = tbl[row[u]] <= qb[u];
-            pos[u] = (tbl[row[u] + 4] <= qb[u]) ? 4u : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < N; u++) pos[u] += (tbl[row[u] + pos[u] + 2] <= qb[u]) ? 2u : 0u;
-#pragma unroll
-        for (int u = 0; u < N; u++) pos[u] += (tbl[row[u] + pos[u] + 1] <= qb[u]) ? 1u : 0u;
-#pragma unroll
-        for (int u = 0; u < N; u++) {
-            const uint32_t cnt = pos[u] + tiny[u];
-            unsigned bin = pos_dir[u] ? base[u] + cnt : base[u] - cnt;
-            if (live[u]) {
-                if (!ok[u]) bin = pc_alpha_bin_exact(v[u].x, v[u].y, vy, vz);   /* zero/inf/NaN: full formula */
-                if (bin < OSLAMK_NBIN) atomicAdd(&acc[mr[u] * OSLAMK_NBIN + bin], 1u);
-            }
-        }
-    }
-};
-
-template <>
-struct Chunk<1> {                      /* fast mode: 8-byte entries */
-    static constexpr int U = FAST_U;
-    uint2 v[U];
-    __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
-                                         uint32_t ln, int lane)
+    __device__ __forceinline__ void vote(const oslamk_vote_args &a, uint32_t *acc, const uint32_t *tbl,
+                                         uint32_t st, uint32_t off, uint32_t ln, int lane, uint32_t cs,
+                                         float vy, float vz) const
     {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t idx = off + u * WAVE + lane;
-            if (idx < ln) v[u] = *reinterpret_cast<const uint2 *>(&a.ent.fast[(size_t)st + idx]);
-        }
-    }
-    __device__ __forceinline__ void vote(uint32_t *acc, const uint32_t *, uint32_t m_base,
-                                         uint32_t off, uint32_t ln, int lane, float cs, float) const
-    {
+            const uint32_t e = off + 4u * (u * WAVE + lane);
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t idx = off + u * WAVE + lane;
-            if (idx < ln) {
-                float t = cs - __builtin_bit_cast(float, v[u].y);   /* in [15, 75] */
-                t = t >= 30.0f ? t - 30.0f : t;
-                t = t >= 30.0f ? t - 30.0f : t;
-                const unsigned bin = (unsigned)(int)t;
-                if (bin < OSLAMK_NBIN) atomicAdd(&acc[(v[u].x - m_base) * OSLAMK_NBIN + bin], 1u);
+            for (int j = 0; j < 4; j++) {
+                if (e + j < ln) {
+                    const uint32_t am = w[j] & 0x3fffffu, mr = w[j] >> 22;
+                    const uint32_t t = pc_turn_q17(cs, am);
+                    unsigned bin = t >> 17;
+                    if (MODE == 0 && pc_turn_needs_exact(t, cs, am)) {
+                        const float2 uv = *reinterpret_cast<const float2 *>(&a.ent.uv[(size_t)st + e + j]);
+                        bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, tbl);
+                    }
+                    if (bin < OSLAMK_NBIN) atomicAdd(&acc[mr * OSLAMK_NBIN + bin], 1u);
+                }
             }
         }
     }
@@ -330,7 +256,7 @@ struct Chunk<1> {                      /* fast mode: 8-byte entries */
 /* Scene::Scene's key pass (scene.cu:24-55: K1 ppf_kernel + K2 ppf_hash_kernel) fused with
  * the lookup of model.cu:96-97: one thread per scene pair (reference point r, point i).
  * Pairs whose key is in the model (union of all slices) are appended to r's hit list as
- * {key, (T_s_g*s_i).y, (T_s_g*s_i).z, i}; one atomic per wave reserves the slots.
+ * {key, (T_s_g*s_i).y, (T_s_g*s_i).z, theta_v}; one atomic per wave reserves the slots.
  * grid (ceil(S/256), refs in this batch). */
 __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 {
@@ -361,9 +287,8 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
                 const float *rows = a.tsg + 8 * (size_t)ref_ord;
                 float vy = pc_row_dot(rows, x, y, z);         /* kernel.cu:334-336 */
                 float vz = pc_row_dot(rows + 4, x, y, z);
-                if (a.mode == 1) vy = (pm_atan2f(vz, vy) + PM_PI_F) / PM_D_ANGLE + 45.0f;
                 rec = make_uint4(key, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz),
-                                 (uint32_t)i);
+                                 pc_angle_q17(vy, vz));
             }
         }
     }
@@ -409,13 +334,13 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 
     const oslamk_slot *tab = a.table.slots + (size_t)slice * a.table.cap;
     const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
-    const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;
+    const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
     unsigned long long my_hits = 0, my_votes = 0;
     __syncthreads();
 
     for (uint32_t base = 0; base < n_hits; base += VOTE_THREADS) {
         const uint32_t h = base + tid;
-        uint32_t start = 0, len = 0;
+        uint32_t start = 0, len = 0, cs = 0;
         float vy = 0.0f, vz = 0.0f;
         if (h < n_hits) {
             const uint4 rec = hits[h];
@@ -433,6 +358,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             }
             vy = __builtin_bit_cast(float, rec.y);
             vz = __builtin_bit_cast(float, rec.z);
+            cs = rec.w;
             if (slice == 0) my_hits += 1;
         }
         /* wave-cooperative sweep: all 64 lanes stream one bucket at a time, in chunks of
@@ -441,22 +367,23 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         unsigned long long todo = __ballot(len > 0);
         if (todo) {
             int l = __ffsll((long long)todo) - 1;
-            uint32_t st = readlane_u(start, l), ln = readlane_u(len, l), off = 0;
+            uint32_t st = readlane_u(start, l), ln = readlane_u(len, l), csl = readlane_u(cs, l), off = 0;
             float vyl = readlane_f(vy, l), vzl = readlane_f(vz, l);
             CH nxt;
             nxt.load(a, st, off, ln, lane);
             for (;;) {
                 const CH cur = nxt;
-                const uint32_t coff = off, cln = ln;
+                const uint32_t cst = st, coff = off, cln = ln, ccs = csl;
                 const float cvy = vyl, cvz = vzl;
                 bool more = true;
-                off += CH::U * WAVE;
+                off += CH::U * WAVE * 4;
                 if (off >= ln) {
                     todo &= todo - 1;
                     if (todo) {
                         l = __ffsll((long long)todo) - 1;
                         st = readlane_u(start, l);
                         ln = readlane_u(len, l);
+                        csl = readlane_u(cs, l);
                         vyl = readlane_f(vy, l);
                         vzl = readlane_f(vz, l);
                         off = 0;
@@ -465,7 +392,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                     }
                 }
                 if (more) nxt.load(a, st, off, ln, lane);
-                cur.vote(acc, s_tbl, m_base, coff, cln, lane, cvy, cvz);
+                cur.vote(a, acc, s_tbl, cst, coff, cln, lane, ccs, cvy, cvz);
                 if (!more) break;
             }
         }

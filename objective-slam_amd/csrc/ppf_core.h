@@ -111,4 +111,60 @@ PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const 
     return pc_alpha_bin_exact(uy, uz, vy, vz);
 }
 
+/* ---- quantised-angle voting -------------------------------------------------
+ * In exact arithmetic alpha = theta_v - theta_u with theta = atan2(z, y) of the
+ * transformed second points (Drost).  A model pair stores theta_u, a scene pair
+ * theta_v, both as (theta + pi)/D in units of 2^-17 bin; their difference gives
+ * bin and position inside the bin with integer arithmetic.  The float rounding of
+ * the reference's own sequence (cross/dot products, atan2f, + pi, quantisation)
+ * moves alpha by < 2e-5 bin against this value (bound in DESIGN.md), so whenever
+ * the position is further than PC_Q17_MARGIN = 2^-10 bin from a bin edge the bin
+ * is the reference's; otherwise the vote is re-evaluated with pc_alpha_bin_table.
+ * Result: identical bins at a fraction of the arithmetic and 4 bytes per vote. */
+#define PC_Q17_ONE 131072u                    /* 2^17 units per bin */
+#define PC_Q17_TURN (30u * PC_Q17_ONE)       /* one full turn */
+#define PC_Q17_MARGIN 128u                    /* 2^-10 bin */
+#define PC_Q17_FORCE 0x3fffffu                /* "always re-evaluate" marker (fits 22 bits, > PC_Q17_TURN) */
+
+/* (atan2(z, y) + pi) / D in units of 2^-17 bin, in [0, PC_Q17_TURN]; PC_Q17_FORCE when the
+ * vector is zero, not finite or outside 2^-40..2^40, where the products of kernel.cu:84,52
+ * could overflow or lose the vector to underflow and the error bound would not hold */
+PM_HD uint32_t pc_angle_q17(float y, float z)
+{
+    const uint32_t by = PM_BITS_F2U(y) & 0x7fffffffu, bz = PM_BITS_F2U(z) & 0x7fffffffu;
+    const uint32_t e = (by > bz ? by : bz) >> 23;
+    const float t = (pm_atan2f(z, y) + PM_PI_F) / PM_D_ANGLE;
+    const float q = __builtin_rintf(t * 131072.0f);
+    if (e < 87u || e > 167u || !(q >= 0.0f && q <= 3932160.0f)) return PC_Q17_FORCE;
+    return (uint32_t)q;
+}
+
+/* position of alpha + pi on the turn: ((theta_v - theta_u) + pi) mod 2 pi */
+PM_HD uint32_t pc_turn_q17(uint32_t cs_q17, uint32_t am_q17)
+{
+    uint32_t t = cs_q17 + 15u * PC_Q17_ONE + PC_Q17_TURN - am_q17;   /* in (0, 75*2^17] */
+    t = t >= PC_Q17_TURN ? t - PC_Q17_TURN : t;
+    t = t >= PC_Q17_TURN ? t - PC_Q17_TURN : t;
+    return t;
+}
+
+/* 1 when the quantised position cannot decide the bin: too close to a bin edge, or one of
+ * the two angles carries the marker */
+PM_HD int pc_turn_needs_exact(uint32_t t, uint32_t cs_q17, uint32_t am_q17)
+{
+    const uint32_t f = t & (PC_Q17_ONE - 1u);
+    return f < PC_Q17_MARGIN || f >= PC_Q17_ONE - PC_Q17_MARGIN || cs_q17 == PC_Q17_FORCE ||
+           am_q17 == PC_Q17_FORCE;
+}
+
+/* the reference's bin from the stored quantities (host-side statement of what the
+ * vote kernel does; used by the CPU check of the scheme) */
+PM_HD unsigned pc_alpha_bin_hybrid(float uy, float uz, float vy, float vz, const uint32_t *tbl)
+{
+    const uint32_t cs = pc_angle_q17(vy, vz), am = pc_angle_q17(uy, uz);
+    const uint32_t t = pc_turn_q17(cs, am);
+    if (pc_turn_needs_exact(t, cs, am)) return pc_alpha_bin_table(uy, uz, vy, vz, tbl);
+    return t >> 17;
+}
+
 #endif /* OSLAM_PPF_CORE_H */

@@ -7,6 +7,8 @@
  *   math_exhaustive atan2f N        N pseudo-random + structured (y,x) pairs
  *   math_exhaustive quant  N        pm_quant_down_pos vs x - fmodf(x, step)
  *   math_exhaustive alphabin N      pc_alpha_bin_table vs the libm formula of kernel.cu:338-342
+ *   math_exhaustive hybrid N        pc_alpha_bin_hybrid vs the same formula; also prints the largest
+ *                                   distance between the quantised and the reference position
  *
  * Prints "mismatches=K checked=N" and exits non-zero when K != 0.
  * NaN results compare equal when both are NaN (payload is canonicalised by the
@@ -27,6 +29,8 @@ static uint64_t splitmix(uint64_t *s)
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
+
+static int cs_ok(float y, float z) { return pc_angle_q17(y, z) != PC_Q17_FORCE; }
 
 static int same(float a, float b)
 {
@@ -122,8 +126,11 @@ int main(int argc, char **argv)
                 if (bad < 5) fprintf(stderr, "quant(%a,%a): pm=%a libm=%a\n", x, step, a, b);
             }
         }
-    } else if (!strcmp(mode, "alphabin")) {
-#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+    } else if (!strcmp(mode, "alphabin") || !strcmp(mode, "hybrid")) {
+        const int hybrid = !strcmp(mode, "hybrid");
+        double worst = 0.0;
+        uint64_t slow = 0;
+#pragma omp parallel for reduction(+ : bad, checked, slow) reduction(max : worst) schedule(static)
         for (uint64_t i = 0; i < arg; i++) {
             uint64_t s = i * 0xd1342543de82ef95ull + 99;
             uint64_t r = splitmix(&s), r2 = splitmix(&s);
@@ -139,23 +146,40 @@ int main(int argc, char **argv)
                 if ((i & 7) == 1) { vy = uy; vz = uz; }              /* alpha = 0 */
                 if ((i & 7) == 2) { vy = -uy; vz = -uz; }            /* alpha = +-pi */
                 if ((i & 7) == 3) { vy = -uz; vz = uy; }             /* alpha = pi/2 */
+                if ((i & 7) == 5) {                                  /* magnitudes from 2^-50 to 2^50 */
+                    float su = ldexpf(1.0f, (int)((r2 >> 3) % 101) - 50), sv = ldexpf(1.0f, (int)((r2 >> 13) % 101) - 50);
+                    uy *= su; uz *= su; vy *= sv; vz *= sv;
+                }
                 if ((i & 7) == 4) {                                  /* on a bin edge: alpha = 12 deg * j */
                     double a = 0.20943951023931953 * (double)((r2 >> 7) % 30), c = cos(a), sn = sin(a);
                     vy = (float)(uy * c - uz * sn); vz = (float)(uy * sn + uz * c);
                 }
             }
-            unsigned a = pc_alpha_bin_table(uy, uz, vy, vz, &PC_ALPHA_THR[0][0]);
+            unsigned a = hybrid ? pc_alpha_bin_hybrid(uy, uz, vy, vz, &PC_ALPHA_THR[0][0])
+                                : pc_alpha_bin_table(uy, uz, vy, vz, &PC_ALPHA_THR[0][0]);
             /* the reference's own sequence with libm (kernel.cu:338-342) */
             float cx = uy * vz - uz * vy, dt = 0.0f * 0.0f + uy * vy + uz * vz;
             float al = atan2f(cx, dt) + PM_PI_F;
             float aq = al - fmodf(al, PM_D_ANGLE);
             unsigned b = isnan(aq) ? 255u : (unsigned)lrintf(aq / PM_D_ANGLE);
             checked++;
+            if (hybrid && b != 255u && (i & 7) != 7 && cs_ok(uy, uz) && cs_ok(vy, vz)) {
+                /* distance (in bins, on the circle) between the quantised position and the
+                 * reference's alpha + pi: the quantity the margin has to cover */
+                uint32_t cs = pc_angle_q17(vy, vz), am = pc_angle_q17(uy, uz);
+                uint32_t t = pc_turn_q17(cs, am);
+                double d = fabs((double)t / 131072.0 - (double)al / (double)PM_D_ANGLE);
+                if (d > 15.0) d = fabs(d - 30.0);
+                if (d > worst) worst = d;
+                slow += (uint64_t)pc_turn_needs_exact(t, cs, am);
+            }
             if (a != b) {
                 bad++;
                 if (bad < 5) fprintf(stderr, "alphabin(%a,%a,%a,%a): table=%u libm=%u\n", uy, uz, vy, vz, a, b);
             }
         }
+        if (hybrid) printf("largest |quantised - reference| = %.3g bin (margin %.3g); re-evaluated %.4f%%\n", worst,
+                           (double)PC_Q17_MARGIN / 131072.0, 100.0 * (double)slow / (double)checked);
     } else {
         return 2;
     }
