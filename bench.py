@@ -141,11 +141,19 @@ def main():
 
     if rank == 0:
         st = stats_acc[-1]
-        ms_vote = float(np.mean([s["ms_vote"] for s in stats_acc]))      # HIP events on the launch stream
-        # algorithmic bytes of one vote launch: scene points + normals read once,
-        # 8 B per probed scene pair, 8 B per vote (one model-pair entry), 16 B per emitted record
-        bytes_alg = 24.0 * S + 8.0 * st["num_scene_ppfs"] + 8.0 * st["num_votes"] + 16.0 * st["num_emitted"]
-        achieved = bytes_alg / (ms_vote * 1e-3) / 1e9
+        n_slices = (M + 1023) // 1024
+        launches = sum(s["vote_launches"] for s in stats_acc)
+        ms_vote_kernel = float(sum(s["ms_vote_kernel"] for s in stats_acc))   # HIP events around each launch
+        ms_key_kernel = float(sum(s["ms_key_kernel"] for s in stats_acc))
+        ms_path = float(np.mean([s["ms_vote"] for s in stats_acc]))
+        # Algorithmic bytes: 8 B per table probe, 8 B per vote (one model-pair
+        # entry), 16 B per emitted peak record; the vote kernel probes each hit once per slice.
+        vote_bytes_step = 8.0 * st["num_votes"] + 8.0 * st["num_hits"] * n_slices + 16.0 * st["num_emitted"]
+        per_launch_bytes = vote_bytes_step * args.steps / launches
+        per_launch_ms = ms_vote_kernel / launches
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        # whole path of one align: scene read once + probe per scene pair + votes + records
+        path_bytes = 24.0 * S + 8.0 * st["num_scene_ppfs"] + 8.0 * st["num_votes"] + 16.0 * st["num_emitted"]
         dt, dr = ppf.ht_dist(T, poses[0][1])
         out = {
             "metric": "scene_ppf_votes_per_sec",
@@ -175,8 +183,13 @@ def main():
                      "ok_at_reference_criterion_12deg_0.1diam": bool(dr < np.radians(12) and dt < 0.1 * diam)},
             "model_build_s": t_build,
             "roofline": {"bound": "hbm", "kernel": "k_vote", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "alg_bytes_per_launch": bytes_alg, "launch_ms": ms_vote,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic(args, M, S, df),
+                         "alg_bytes_per_launch": per_launch_bytes, "launch_ms": per_launch_ms,
+                         "launches_per_step": launches / args.steps,
+                         "key_kernel_ms_per_step": ms_key_kernel / args.steps,
+                         "path_achieved_GBps": path_bytes / (ms_path * 1e-3) / 1e9,
+                         "path_alg_bytes_per_step": path_bytes, "path_kernels_ms_per_step": ms_path,
                          "torch_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -185,6 +198,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, M, S, df):
+    """HBM bytes per vote-kernel launch from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as
+    read), or None when no pass for this workload is on file.  Counters cannot be read from
+    inside the timed process, so this is the one roofline field that is not measured live."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for r in rec.get("runs", []):
+        if (r["model_points"], r["scene_points"], r["ref_point_df"], r["vote_mode"], r["tau_d"]) == \
+                (M, S, df, args.vote_mode, args.tau_d):
+            return r["hbm_bytes_per_vote_launch"]
+    return None
 
 
 def cpu_baseline(mp, mn, sp, sn, df, d_dist):

@@ -67,10 +67,12 @@ typedef struct oslam_stats {
     uint64_t num_top;              /* cells with count > threshold * max */
     uint32_t max_count;            /* largest cell */
     uint32_t num_emitted;          /* records the vote kernel wrote before the final filter */
-    float ms_vote;                 /* vote kernel(s), HIP events on the launch stream */
+    float ms_vote;                 /* scene-key + vote kernels of the call, HIP events on the launch stream */
     float ms_total;                /* whole oslam_align call, host clock */
-    uint32_t vote_launches;
-    uint32_t reserved[5];
+    uint32_t vote_launches;        /* launches of the vote kernel (one per batch of reference points) */
+    float ms_vote_kernel;          /* sum over the vote-kernel launches alone (HIP events around each) */
+    float ms_key_kernel;           /* sum over the scene-key kernel launches alone */
+    uint32_t reserved[3];
 } oslam_stats;
 
 /* One accumulator peak: code = s_r << 32 | m_r << 6 | alpha_idx (kernel.cu:549). */

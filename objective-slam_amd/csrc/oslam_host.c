@@ -443,13 +443,16 @@ done:
 
 /* scene keys + votes over the scene's shard, in batches of reference points; leaves emitted
  * cells in m->d_out */
+#define MAX_BATCH_EVENTS 64
+
 static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
-                     float *ms_out, uint32_t *launches)
+                     float *ms_out, float *ms_vote_kernel, float *ms_key_kernel, uint32_t *launches)
 {
-    int rc = OSLAM_OK, batch = 1, first;
-    hipEvent_t e0 = NULL, e1 = NULL;
+    int rc = OSLAM_OK, batch = 1, first, nb = 0, i;
+    hipEvent_t e0 = NULL, e1 = NULL, ev[3 * MAX_BATCH_EVENTS];
     oslamk_vote_args a;
     hipStream_t st = (hipStream_t)g_stream;
+    memset(ev, 0, sizeof ev);
     rc = ensure_hit_scratch(m, s, &batch);
     if (rc != OSLAM_OK) return rc;
     memset(&a, 0, sizeof a);
@@ -476,21 +479,36 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
     HIPCHK(hipEventRecord(e0, st));
-    for (first = 0; first < s->n_ref; first += batch) {
+    for (first = 0; first < s->n_ref; first += batch, nb++) {
+        const int timed = nb < MAX_BATCH_EVENTS;
         a.first_ref = first;
         a.n_launch = s->n_ref - first < batch ? s->n_ref - first : batch;
         HIPCHK(hipMemsetAsync(m->d_hit_count, 0, sizeof(uint32_t) * (size_t)a.n_launch, st));
+        if (timed) {
+            for (i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ev[3 * nb + i]));
+            HIPCHK(hipEventRecord(ev[3 * nb], st));
+        }
         KCHK(oslamk_scene_hits(&a, g_stream));
+        if (timed) HIPCHK(hipEventRecord(ev[3 * nb + 1], st));
         KCHK(oslamk_vote(&a, g_stream));
+        if (timed) HIPCHK(hipEventRecord(ev[3 * nb + 2], st));
         if (launches) *launches += 1;
     }
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipMemcpyAsync(cnt, m->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, e0, e1));
+    for (i = 0; i < nb && i < MAX_BATCH_EVENTS; i++) {
+        float k = 0.0f, v = 0.0f;
+        HIPCHK(hipEventElapsedTime(&k, ev[3 * i], ev[3 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&v, ev[3 * i + 1], ev[3 * i + 2]));
+        if (ms_key_kernel) *ms_key_kernel += k;
+        if (ms_vote_kernel) *ms_vote_kernel += v;
+    }
 done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    for (i = 0; i < 3 * MAX_BATCH_EVENTS; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
     return rc;
 }
 
@@ -500,13 +518,13 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
                           oslam_stats *st)
 {
     int rc = OSLAM_OK;
-    float ms = 0.0f, ms2 = 0.0f;
+    float ms = 0.0f, ms2 = 0.0f, msv = 0.0f, msk = 0.0f;
     uint32_t launches = 0;
-    rc = run_votes(m, s, 0, cnt, &ms, &launches);
+    rc = run_votes(m, s, 0, cnt, &ms, &msv, &msk, &launches);
     if (rc != OSLAM_OK) return rc;
     if (cnt->out_count > m->out_cap) {
         uint32_t g = cnt->gmax;
-        rc = run_votes(m, s, g, cnt, &ms2, &launches);
+        rc = run_votes(m, s, g, cnt, &ms2, &msv, &msk, &launches);
         if (rc != OSLAM_OK) return rc;
         cnt->gmax = g;
         if (cnt->out_count > m->out_cap)
@@ -525,6 +543,8 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
         st->max_count = cnt->gmax;
         st->num_emitted = cnt->out_count;
         st->ms_vote = ms + ms2;
+        st->ms_vote_kernel = msv;
+        st->ms_key_kernel = msk;
         st->vote_launches = launches;
     }
 done:

@@ -21,8 +21,11 @@
 #include "ppf_core.h"
 
 #define WAVE 64
+#ifndef VOTE_PIPE
+#define VOTE_PIPE 1       /* chunks in flight ahead of the one being voted (1 measured best) */
+#endif
 #ifndef VOTE_U
-#define VOTE_U 2          /* 16-byte loads per lane per chunk: 256*VOTE_U entries per wave */
+#define VOTE_U 1          /* 16-byte loads per lane per chunk: 256*VOTE_U entries per wave */
 #endif
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
@@ -210,10 +213,17 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
+/* which chunk of which bucket (wave-uniform) */
+struct ChunkDesc {
+    uint32_t st, off, ln, cs;
+    float vy, vz;
+    bool valid;
+};
+
 /* A chunk of VOTE_U x 256 model-pair entries held in registers by one wave: lane l holds
  * entries 4*(u*64 + l) .. +3 of the chunk (one 16-byte load each).
  * A vote: theta_v - theta_u in units of 2^-17 bin gives bin and position in the bin; only
- * positions within 2^-10 bin of an edge (0.2 % of votes) are re-evaluated with the reference's
+ * positions within 2^-12 bin of an edge (0.05 % of votes) are re-evaluated with the reference's
  * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's. */
 template <int MODE>
 struct Chunk {
@@ -364,37 +374,60 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         /* wave-cooperative sweep: all 64 lanes stream one bucket at a time, in chunks of
          * CH::U x 64 entries; the next chunk's loads (possibly of the next bucket) are in
          * flight while the current chunk votes */
+        /* chunk generator over this wave's hit buckets (all state wave-uniform) */
         unsigned long long todo = __ballot(len > 0);
-        if (todo) {
-            int l = __ffsll((long long)todo) - 1;
-            uint32_t st = readlane_u(start, l), ln = readlane_u(len, l), csl = readlane_u(cs, l), off = 0;
-            float vyl = readlane_f(vy, l), vzl = readlane_f(vz, l);
-            CH nxt;
-            nxt.load(a, st, off, ln, lane);
-            for (;;) {
-                const CH cur = nxt;
-                const uint32_t cst = st, coff = off, cln = ln, ccs = csl;
-                const float cvy = vyl, cvz = vzl;
-                bool more = true;
-                off += CH::U * WAVE * 4;
-                if (off >= ln) {
+        ChunkDesc g;                       /* the next chunk to hand out */
+        g.valid = todo != 0;
+        if (g.valid) {
+            const int l = __ffsll((long long)todo) - 1;
+            g.st = readlane_u(start, l);
+            g.ln = readlane_u(len, l);
+            g.cs = readlane_u(cs, l);
+            g.vy = readlane_f(vy, l);
+            g.vz = readlane_f(vz, l);
+            g.off = 0;
+        }
+        auto next_chunk = [&]() -> ChunkDesc {
+            const ChunkDesc out = g;
+            if (g.valid) {
+                g.off += CH::U * WAVE * 4;
+                if (g.off >= g.ln) {
                     todo &= todo - 1;
                     if (todo) {
-                        l = __ffsll((long long)todo) - 1;
-                        st = readlane_u(start, l);
-                        ln = readlane_u(len, l);
-                        csl = readlane_u(cs, l);
-                        vyl = readlane_f(vy, l);
-                        vzl = readlane_f(vz, l);
-                        off = 0;
+                        const int l = __ffsll((long long)todo) - 1;
+                        g.st = readlane_u(start, l);
+                        g.ln = readlane_u(len, l);
+                        g.cs = readlane_u(cs, l);
+                        g.vy = readlane_f(vy, l);
+                        g.vz = readlane_f(vz, l);
+                        g.off = 0;
                     } else {
-                        more = false;
+                        g.valid = false;
                     }
                 }
-                if (more) nxt.load(a, st, off, ln, lane);
-                cur.vote(a, acc, s_tbl, cst, coff, cln, lane, ccs, cvy, cvz);
-                if (!more) break;
             }
+            return out;
+        };
+        /* VOTE_PIPE chunks are in flight ahead of the one being voted */
+        ChunkDesc d[VOTE_PIPE];
+        CH c[VOTE_PIPE];
+#pragma unroll
+        for (int i = 0; i < VOTE_PIPE; i++) {
+            d[i] = next_chunk();
+            if (d[i].valid) c[i].load(a, d[i].st, d[i].off, d[i].ln, lane);
+        }
+        while (d[0].valid) {
+            const CH cur = c[0];
+            const ChunkDesc dc = d[0];
+#pragma unroll
+            for (int i = 0; i + 1 < VOTE_PIPE; i++) {
+                c[i] = c[i + 1];
+                d[i] = d[i + 1];
+            }
+            d[VOTE_PIPE - 1] = next_chunk();
+            if (d[VOTE_PIPE - 1].valid)
+                c[VOTE_PIPE - 1].load(a, d[VOTE_PIPE - 1].st, d[VOTE_PIPE - 1].off, d[VOTE_PIPE - 1].ln, lane);
+            cur.vote(a, acc, s_tbl, dc.st, dc.off, dc.ln, lane, dc.cs, dc.vy, dc.vz);
         }
     }
     __syncthreads();

@@ -118,12 +118,12 @@ PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const 
  * bin and position inside the bin with integer arithmetic.  The float rounding of
  * the reference's own sequence (cross/dot products, atan2f, + pi, quantisation)
  * moves alpha by < 2e-5 bin against this value (bound in DESIGN.md), so whenever
- * the position is further than PC_Q17_MARGIN = 2^-10 bin from a bin edge the bin
+ * the position is further than PC_Q17_MARGIN = 2^-12 bin from a bin edge the bin
  * is the reference's; otherwise the vote is re-evaluated with pc_alpha_bin_table.
  * Result: identical bins at a fraction of the arithmetic and 4 bytes per vote. */
 #define PC_Q17_ONE 131072u                    /* 2^17 units per bin */
 #define PC_Q17_TURN (30u * PC_Q17_ONE)       /* one full turn */
-#define PC_Q17_MARGIN 128u                    /* 2^-10 bin */
+#define PC_Q17_MARGIN 32u                     /* 2^-12 bin */
 #define PC_Q17_FORCE 0x3fffffu                /* "always re-evaluate" marker (fits 22 bits, > PC_Q17_TURN) */
 
 /* (atan2(z, y) + pi) / D in units of 2^-17 bin, in [0, PC_Q17_TURN]; PC_Q17_FORCE when the

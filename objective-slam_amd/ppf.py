@@ -40,7 +40,8 @@ class Stats(C.Structure):
     _fields_ = [("num_scene_ppfs", C.c_uint64), ("num_hits", C.c_uint64), ("num_votes", C.c_uint64),
                 ("num_unique_votes", C.c_uint64), ("num_model_keys", C.c_uint64), ("num_top", C.c_uint64),
                 ("max_count", C.c_uint32), ("num_emitted", C.c_uint32), ("ms_vote", C.c_float),
-                ("ms_total", C.c_float), ("vote_launches", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("ms_total", C.c_float), ("vote_launches", C.c_uint32), ("ms_vote_kernel", C.c_float),
+                ("ms_key_kernel", C.c_float), ("reserved", C.c_uint32 * 3)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
