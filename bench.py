@@ -33,7 +33,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-RECORD_CAP = 4096        # peak records all-gathered per GPU (16 B each = 64 KiB)
 
 
 def log(*a):
@@ -90,25 +89,14 @@ def main():
     scene = ppf.Scene(sp, sn, d_dist=d_dist, ref_point_downsample_factor=df, params=par)   # resident in HBM
     log("[rank %d] model build %.3fs, d_dist %.5f, df %d" % (rank, t_build, d_dist, df))
 
-    rec_buf = torch.zeros(RECORD_CAP * 2, dtype=torch.int64, device="cuda")
-    gathered = torch.zeros(world * RECORD_CAP * 2, dtype=torch.int64, device="cuda") if world > 1 else None
-    meta = torch.zeros(2, dtype=torch.int64, device="cuda")
-
     def step():
         if world == 1:
             T = model.ppf_lookup(scene)
             return T, dict(model.stats)
-        cells, lmax = model.align_local(scene, cap=RECORD_CAP)
+        cells, lmax = model.align_local(scene, cap=pkg.dist.RECORD_CAP)     # vote kernels on this shard
         st = dict(model.stats)
-        host = np.zeros(RECORD_CAP * 2, np.int64)
-        host[: 2 * len(cells)] = cells.view(np.int64).reshape(-1) if len(cells) else []
-        rec_buf.copy_(torch.from_numpy(host), non_blocking=False)
-        meta[0] = lmax
-        dist.all_reduce(meta[:1], op=dist.ReduceOp.MAX)                  # global vote maximum
-        dist.all_gather_into_tensor(gathered, rec_buf)                   # per-GPU top pose votes
-        allrec = gathered.cpu().numpy().view(ppf.CELL_DTYPE)
-        allrec = allrec[allrec["count"] > 0]
-        T = model.align_finish(scene, allrec, int(meta[0].item()))       # host-side clustering
+        allrec, gmax = pkg.dist.gather_peaks(cells, lmax, "cuda")           # RCCL all-reduce + all-gather
+        T = model.align_finish(scene, allrec, gmax)                          # host-side clustering
         return T, st
 
     def sync():

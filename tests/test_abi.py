@@ -1,0 +1,91 @@
+"""CPU: the C-ABI library loads, exports every symbol include/oslam.h declares, and its
+host-side stage (poses, clustering, ht_dist) equals the oracle.  No compute call that needs
+the GPU is made; on a machine without a HIP device those calls must fail loudly."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import make_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "oslam.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oslam_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib, ppf):
+    names = declared_symbols()
+    assert len(names) >= 24
+    raw = C.CDLL(ppf.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), n
+    assert set(names) == set(ppf._SIGNATURES), set(names) ^ set(ppf._SIGNATURES)
+
+
+def test_params_default_match_the_reference_cli(built_lib, ppf):
+    p = ppf.default_params()
+    # alignment.cpp:119-172
+    assert p.ref_point_df == 1 and abs(p.vote_count_threshold - 0.4) < 1e-7
+    assert (p.cpu_clustering, p.use_l1_norm, p.use_averaged_clusters) == (0, 0, 0)
+    assert p.vote_mode == ppf.VOTE_EXACT and (p.shard_rank, p.shard_world) == (0, 1)
+
+
+def test_d_dist_rule(built_lib, ppf, synth):
+    mp, _ = synth.make_model(0, 300)
+    assert ppf.d_dist_from_cloud(mp, 0.05) == synth.d_dist_for(mp, 0.05)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(cpu_clustering=True), dict(use_l1_norm=True),
+                                   dict(use_averaged_clusters=True)])
+def test_host_stage_equals_oracle(built_lib, ppf, oracle, synth, flags):
+    c = make_case(synth, 150, 320, 2020)
+    cells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 1, c["d"])
+    rc, To = oracle.pose_from_cells(cells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], **flags)
+    Tp, poses = ppf.pose_stage(cells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], **flags)
+    assert np.array_equal(Tp, To)
+    assert np.array_equal(poses, oracle.trans_calc2(cells, c["mp"], c["mn"], c["sp"], c["sn"]))
+    assert ppf.ht_dist(Tp, c["truth"]) == oracle.ht_dist(Tp, c["truth"])
+    # weights: all ones is the reference default (model.cu:67); halving them halves cluster scores only
+    Tw, _ = ppf.pose_stage(cells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], weights=np.ones(len(c["mp"])), **flags)
+    assert np.array_equal(Tw, Tp)
+
+
+def test_host_stage_single_and_empty(built_lib, ppf, oracle, synth):
+    c = make_case(synth, 60, 120, 2011)
+    cells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 1, c["d"])
+    T, _ = ppf.pose_stage(cells[:1], c["mp"], c["mn"], c["sp"], c["sn"], c["d"])
+    assert np.all(T == 0)                               # kernel.cu:609: one cell, no pose
+    with pytest.raises(ppf.OslamError):
+        ppf.pose_stage(cells[:0], c["mp"], c["mn"], c["sp"], c["sn"], c["d"])
+    bad = cells[:2].copy()
+    bad["code"][0] = (1 << 40)                          # scene index out of range
+    with pytest.raises(ppf.OslamError):
+        ppf.pose_stage(bad, c["mp"], c["mn"], c["sp"], c["sn"], c["d"])
+
+
+def test_filter_and_sort(built_lib, ppf):
+    cells = np.zeros(6, ppf.CELL_DTYPE)
+    cells["code"] = [5, 3, 9, 1, 7, 2]
+    cells["count"] = [10, 4, 10, 5, 3, 4]
+    L = ppf.lib()
+    n = L.oslam_filter_cells(cells.ctypes.data_as(C.c_void_p), 6, 0.4, 10)    # keep count > 4.0
+    assert n == 3
+    kept = cells[:n].copy()
+    L.oslam_sort_cells(kept.ctypes.data_as(C.c_void_p), n)
+    assert list(kept["code"]) == [5, 9, 1] and list(kept["count"]) == [10, 10, 5]
+
+
+def test_no_cpu_fallback(built_lib, ppf, synth):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    mp, mn = synth.make_model(0, 50)
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Model(mp, mn, d_dist=0.1)
+    assert e.value.code == ppf.OSLAM_E_DEVICE and "no CPU fallback" in str(e.value)

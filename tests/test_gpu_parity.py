@@ -166,3 +166,110 @@ def test_ppf_registration_entry_point(ppf, oracle, built_lib, synth):
         ocells, _ = oracle.votes_fused(c["mp"], c["mn"], a["sp"], a["sn"], 2, c["d"], 0.4)
         rc, To = oracle.pose_from_cells(ocells, c["mp"], c["mn"], a["sp"], a["sn"], c["d"])
         assert np.array_equal(res[0, j], To)
+
+
+# ---------------------------------------------------------------------------
+# committed fixtures and BASELINE.json-size properties
+# ---------------------------------------------------------------------------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["case_m64_s128", "case_m200_s400_df3"])
+def test_golden_fixtures_on_gpu(ppf, built_lib, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    d, df = float(g["d_dist"]), int(g["df"])
+    sc = ppf.Scene(g["sp"], g["sn"], d_dist=d, ref_point_downsample_factor=df)
+    mo = ppf.Model(g["mp"], g["mn"], d_dist=d)
+    for r in (0, 7, len(g["mp"]) - 1):
+        assert np.array_equal(mo.getHashKeys(r), g["model_keys"][r])
+    assert np.array_equal(sc.getHashKeys(0), g["scene_keys_row0"])
+    T = mo.ppf_lookup(sc)
+    cells, poses = mo.last_cells()
+    assert np.array_equal(cells["code"], g["cell_code"]) and np.array_equal(cells["count"], g["cell_count"])
+    # poses involve libm sinf/cosf of the host that wrote the fixture: last-bit tolerance
+    np.testing.assert_allclose(poses, g["poses"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(T, g["T_gpu"], rtol=0, atol=2e-5)
+    mo2 = ppf.Model(g["mp"], g["mn"], d_dist=d, cpu_clustering=True)
+    np.testing.assert_allclose(mo2.ppf_lookup(sc), g["T_cpu"], rtol=0, atol=2e-5)
+
+
+def test_record_buffer_overflow_takes_the_second_pass(ppf, oracle, built_lib, case_small):
+    c = case_small
+    par = ppf.default_params(max_cells=8)          # far fewer than the cells the first pass emits
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], params=par)
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
+    ocells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 1, c["d"], 0.4)
+    if len(ocells) > 8:
+        with pytest.raises(ppf.OslamError):        # even the exact set does not fit: reported, not truncated
+            mo.ppf_lookup(sc)
+    par = ppf.default_params(max_cells=max(16, 2 * len(ocells)))
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
+    mo.ppf_lookup(sc)
+    assert cells_equal(mo.last_cells()[0], ocells) and mo.stats["vote_launches"] >= 1
+
+
+@pytest.fixture(scope="module")
+def full_size(synth):
+    """BASELINE.json metric configuration: 5k-point model, 100k-point scene."""
+    mp, mn = synth.make_model(0, 5000)
+    d = synth.d_dist_for(mp, 0.025)
+    sp, sn, poses = synth.make_scene([0], 100000, 2002, instance_points=5000, noise_sigma=0.1 * d)
+    return dict(mp=mp, mn=mn, sp=sp, sn=sn, d=d, truth=poses[0][1], diam=synth.bbox_extent(mp))
+
+
+def test_full_size_sample_against_oracle(ppf, oracle, built_lib, full_size):
+    """Five reference points of the 5k x 100k workload: dense accumulators against the oracle's
+    per-reference counters (sum = votes, non-empty cells, maximum) and the 10 largest cells."""
+    c = full_size
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=8)
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+    fm = oracle.FusedModel(c["mp"], c["mn"], c["d"])
+    assert mo.bucket(int(mo.getHashKeys(0)[1]))[1] > 0
+    for k in (0, 17, 402, 6000, 12499):
+        ocells, st = fm.votes(c["sp"], c["sn"], 8, thresh=0.0, ref_begin=k, ref_limit=1)
+        acc = mo.vote_accumulator(sc, 8 * k)
+        assert int(acc.sum()) == st["num_votes"]
+        assert int(np.count_nonzero(acc)) == st["num_unique_votes"]
+        assert int(acc.max()) == st["max_count"]
+        top = ocells[:10]
+        got = acc[((top["code"] & 0xFFFFFFFF) >> 6).astype(int), (top["code"] & 63).astype(int)]
+        assert np.array_equal(got, top["count"])
+    fm.close()
+
+
+def test_full_size_properties(ppf, built_lib, full_size):
+    c = full_size
+    par = ppf.default_params()
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=8, params=par)
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
+    T1 = mo.ppf_lookup(sc)
+    cells1, st1 = mo.last_cells()[0], dict(mo.stats)
+    T2 = mo.ppf_lookup(sc)                                           # determinism / idempotence
+    assert np.array_equal(T1, T2) and cells_equal(cells1, mo.last_cells()[0])
+    assert st1["num_scene_ppfs"] == 12500 * 99999
+    # shards partition the votes and their union reproduces the single-GPU cells and pose
+    tot_votes = tot_hits = 0
+    parts, gmax = [], 0
+    for rank in range(2):
+        ps = ppf.default_params(shard_rank=rank, shard_world=2)
+        scs = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=8, params=ps)
+        loc, lmax = mo.align_local(scs, cap=1 << 16)
+        tot_votes += mo.stats["num_votes"]
+        tot_hits += mo.stats["num_hits"]
+        parts.append(loc)
+        gmax = max(gmax, lmax)
+    assert (tot_votes, tot_hits, gmax) == (st1["num_votes"], st1["num_hits"], st1["max_count"])
+    T3 = mo.align_finish(sc, np.concatenate(parts), gmax)
+    assert np.array_equal(T3, T1) and cells_equal(mo.last_cells()[0], cells1)
+    # pose against ground truth at the reference's own acceptance test (alignment.cpp:141-144,317-323)
+    dt, dr = ppf.ht_dist(T1, c["truth"])
+    assert dr < np.deg2rad(12) and dt < 0.1 * c["diam"]
+    # fast mode (no re-evaluation near bin edges): pose within 1 deg / 1 % of the diameter of exact
+    pf = ppf.default_params(vote_mode=ppf.VOTE_FAST)
+    mf = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=pf)
+    Tf = mf.ppf_lookup(ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=8, params=pf))
+    dtf, drf = ppf.ht_dist(Tf, T1)
+    assert drf < np.deg2rad(1.0) and dtf < 0.01 * c["diam"]
+    assert mf.stats["num_votes"] == st1["num_votes"] and mf.stats["max_count"] >= 0.99 * st1["max_count"]
