@@ -1,0 +1,48 @@
+// Compile-and-link check of include/oslam_pcl.hpp with plain structs shaped like
+// pcl::PointNormal / pcl::PointCloud / Eigen::Matrix4f (none of which are in this image).
+// With a GPU it also runs one registration and prints the pose.
+#include <cstdio>
+#include <memory>
+#include <type_traits>
+#include <vector>
+
+#include "oslam_pcl.hpp"
+
+struct alignas(16) PointNormal {          // 48 bytes, like pcl::PointNormal
+    float x, y, z, pad0;
+    float normal_x, normal_y, normal_z, pad1;
+    float curvature, pad2[3];
+};
+struct Cloud {
+    std::vector<PointNormal> pts;
+    std::size_t size() const { return pts.size(); }
+    const PointNormal &operator[](std::size_t i) const { return pts[i]; }
+    PointNormal &operator[](std::size_t i) { return pts[i]; }
+};
+struct Mat4 {
+    float m[4][4];
+    float &operator()(int r, int c) { return m[r][c]; }
+};
+
+int main(int argc, char **argv)
+{
+    static_assert(sizeof(PointNormal) == 48, "layout");
+    auto model = std::make_shared<Cloud>(), scene = std::make_shared<Cloud>();
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; };
+    for (int i = 0; i < 80; i++) {
+        PointNormal p{};
+        p.x = rnd(); p.y = rnd(); p.z = 0.3f * rnd();
+        p.normal_x = 0.1f * rnd(); p.normal_y = 0.1f * rnd(); p.normal_z = 1.0f;
+        model->pts.push_back(p);
+        p.x += 2.0f; p.y -= 1.0f;           // the scene is the model, translated
+        scene->pts.push_back(p);
+    }
+    if (argc > 1) {                         // "run": needs a GPU
+        auto res = oslam::ppf_registration<Mat4>(std::vector<std::shared_ptr<Cloud>>{scene},
+                                                 std::vector<std::shared_ptr<Cloud>>{model},
+                                                 std::vector<float>{0.05f}, 1, 0.4f, false, false, false, 0, nullptr);
+        std::printf("t = %.3f %.3f %.3f\n", res[0][0](0, 3), res[0][0](1, 3), res[0][0](2, 3));
+    }
+    return 0;
+}

@@ -89,3 +89,16 @@ def test_no_cpu_fallback(built_lib, ppf, synth):
     with pytest.raises(ppf.OslamError) as e:
         ppf.Model(mp, mn, d_dist=0.1)
     assert e.value.code == ppf.OSLAM_E_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_cpp_adaptor_compiles_and_links(built_lib, ppf):
+    """include/oslam_pcl.hpp (the reference's C++ signatures over the C-ABI) with plain structs
+    shaped like pcl::PointNormal / Eigen::Matrix4f; PCL and Eigen are not in this image."""
+    import subprocess
+    out = os.path.join(ROOT, "build", "pcl_adaptor_check")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    libdir = os.path.dirname(ppf.LIB_PATH)
+    subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "native", "pcl_adaptor_check.cpp"), "-o", out,
+                    "-L", libdir, "-loslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    assert subprocess.run([out]).returncode == 0

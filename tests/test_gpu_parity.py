@@ -273,3 +273,19 @@ def test_full_size_properties(ppf, built_lib, full_size):
     dtf, drf = ppf.ht_dist(Tf, T1)
     assert drf < np.deg2rad(1.0) and dtf < 0.01 * c["diam"]
     assert mf.stats["num_votes"] == st1["num_votes"] and mf.stats["max_count"] >= 0.99 * st1["max_count"]
+
+
+def test_cpp_adaptor_runs(ppf, built_lib):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "build", "pcl_adaptor_check_gpu")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    libdir = os.path.dirname(ppf.LIB_PATH)
+    subprocess.run(["g++", "-std=c++14", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "native", "pcl_adaptor_check.cpp"), "-o", out,
+                    "-L", libdir, "-loslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([out, "run"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    t = [float(x) for x in r.stdout.split("=")[1].split()]
+    # the scene is the model shifted by (2, -1, 0); bin-accurate recovery (d_dist = 0.05)
+    assert abs(t[0] - 2.0) < 0.3 and abs(t[1] + 1.0) < 0.3 and abs(t[2]) < 0.3
