@@ -14,7 +14,7 @@ ranks per second.
 
 Multi-GPU: one process per GPU; scene reference points are dealt round-robin to
 ranks (no data-path collective); per step an RCCL all-reduce(MAX) of the local
-vote maximum and an all-gather of fixed-size peak records, then the host stage.
+vote maximum and an all-gather of the records above the global threshold, then the host stage.
 Weak scaling: ref_point_df = 8 / N keeps 12.5k reference points per GPU.
 
 One JSON line on stdout (rank 0); progress goes to stderr.
@@ -64,10 +64,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # OSLAM_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks
+    # (ranks share devices, the exchange runs on CPU tensors); the driver's runs use nccl = RCCL.
+    backend = os.environ.get("OSLAM_BENCH_BACKEND", "nccl")
+    xdev = "cuda" if backend == "nccl" else "cpu"
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("objective-slam_amd")
     ppf, synth = pkg.ppf, pkg.synth
@@ -80,7 +85,7 @@ def main():
     diam = synth.bbox_extent(mp)
 
     mode = ppf.VOTE_FAST if args.vote_mode == "fast" else ppf.VOTE_EXACT
-    par = ppf.default_params(dev=local_rank, shard_rank=rank, shard_world=world, vote_mode=mode)
+    par = ppf.default_params(dev=dev_index, shard_rank=rank, shard_world=world, vote_mode=mode)
     stream = torch.cuda.current_stream()
     ppf.set_stream(stream.cuda_stream)
     t0 = time.time()
@@ -93,9 +98,9 @@ def main():
         if world == 1:
             T = model.ppf_lookup(scene)
             return T, dict(model.stats)
-        cells, lmax = model.align_local(scene, cap=pkg.dist.RECORD_CAP)     # vote kernels on this shard
+        cells, lmax = model.align_local(scene, cap=pkg.dist.LOCAL_CAP)      # vote kernels on this shard
         st = dict(model.stats)
-        allrec, gmax = pkg.dist.gather_peaks(cells, lmax, "cuda")           # RCCL all-reduce + all-gather
+        allrec, gmax = pkg.dist.gather_peaks(cells, lmax, xdev)             # RCCL all-reduce + all-gather
         T = model.align_finish(scene, allrec, gmax)                          # host-side clustering
         return T, st
 
@@ -118,9 +123,9 @@ def main():
     ev1.record(stream)
     sync()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
     ppfs = torch.tensor([float(sum(s["num_scene_ppfs"] for s in stats_acc)),
-                         float(sum(s["num_votes"] for s in stats_acc))], dtype=torch.float64, device="cuda")
+                         float(sum(s["num_votes"] for s in stats_acc))], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ppfs, op=dist.ReduceOp.SUM)

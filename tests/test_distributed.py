@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
     df = 2
     # this rank's shard: reference points df*(rank + world*t), as oslam_scene_create deals them
     local, st = O.votes_fused(m_p, m_n, s_p, s_n, df, d, 0.4, ref_begin=rank, ref_step=world)
-    allrec, gmax = pkg.dist.gather_peaks(local, st["max_count"], "cpu")
+    allrec, gmax = pkg.dist.gather_peaks(local, st["max_count"], "cpu", 0.4)
     T, kept = pkg.dist.finish_on_host(allrec, gmax, m_p, m_n, s_p, s_n, d)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), T=T, code=kept["code"], count=kept["count"], gmax=gmax)
     dist.barrier()
