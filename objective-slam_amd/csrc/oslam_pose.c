@@ -121,19 +121,53 @@ size_t oslam_filter_cells(oslam_cell *cells, size_t n, float thresh, uint32_t gm
     return k;
 }
 
-/* ---- K5: pose of one cell (kernel.cu:372-401) ---- */
-static void cell_pose(uint64_t code, const float *m_xyz, const float *m_nrm, const float *s_xyz,
-                      const float *s_nrm, float *T)
+/* ---- K5: pose of one cell (kernel.cu:372-401) from the two frames ---- */
+static void cell_pose(uint64_t code, const float *Tm, const float *Ts, float *T)
 {
-    uint32_t s = (uint32_t)(code >> 32), mac = (uint32_t)code;
-    uint32_t m = mac >> 6, a = mac & 63u;
-    float Tm[16], Ts[16], rx[16], inv[16], tmp[16];
-    oslam_build_T_g(m_xyz + 3 * (size_t)m, m_nrm + 3 * (size_t)m, Tm);
-    oslam_build_T_g(s_xyz + 3 * (size_t)s, s_nrm + 3 * (size_t)s, Ts);
+    uint32_t a = ((uint32_t)code) & 63u;
+    float rx[16], inv[16], tmp[16];
     mat_rot(0, a * POSE_D - POSE_PI, rx);
     mat_inv_rigid(Ts, inv);
     mat_mul(inv, rx, tmp);
     mat_mul(tmp, Tm, T);
+}
+
+/* T_g of every distinct point index that occurs in the cells, computed once each (many cells
+ * share a reference point); `which` = 0: scene index (high word), 1: model index */
+typedef struct { uint32_t *idx; float *T; size_t n; } frame_cache;
+
+static int u32_cmp(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : (x > y);
+}
+
+static int frame_cache_build(frame_cache *fc, const oslam_cell *cells, size_t n, int which,
+                             const float *xyz, const float *nrm)
+{
+    size_t i, u = 0;
+    fc->idx = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    if (!fc->idx) return -1;
+    for (i = 0; i < n; i++)
+        fc->idx[i] = which ? (((uint32_t)cells[i].code) >> 6) : (uint32_t)(cells[i].code >> 32);
+    qsort(fc->idx, n, sizeof(uint32_t), u32_cmp);
+    for (i = 0; i < n; i++)
+        if (i == 0 || fc->idx[i] != fc->idx[i - 1]) fc->idx[u++] = fc->idx[i];
+    fc->n = u;
+    fc->T = (float *)malloc(sizeof(float) * 16 * (u ? u : 1));
+    if (!fc->T) return -1;
+    for (i = 0; i < u; i++) oslam_build_T_g(xyz + 3 * (size_t)fc->idx[i], nrm + 3 * (size_t)fc->idx[i], fc->T + 16 * i);
+    return 0;
+}
+
+static const float *frame_cache_get(const frame_cache *fc, uint32_t idx)
+{
+    size_t lo = 0, hi = fc->n;
+    while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        if (fc->idx[mid] < idx) lo = mid + 1; else hi = mid;
+    }
+    return fc->T + 16 * lo;
 }
 
 /* ---- K7 (kernel.cu:128-144): q = (w,x,y,z) ---- */
@@ -361,10 +395,17 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
     poses = (float *)calloc(16 * n, sizeof(float));
     if (!poses) return OSLAM_E_NOMEM;
     if (n > 1) {                                   /* kernel.cu:609: a single cell yields no pose */
+        frame_cache fs = {0, 0, 0}, fm = {0, 0, 0};
+        if (frame_cache_build(&fs, cells, n, 0, s_xyz, s_nrm) || frame_cache_build(&fm, cells, n, 1, m_xyz, m_nrm)) {
+            free(fs.idx); free(fs.T); free(fm.idx); free(fm.T); free(poses);
+            return OSLAM_E_NOMEM;
+        }
         for (i = 0; i < n; i++) {
             if ((cells[i].code >> 32) == 0 && ((uint32_t)cells[i].code) == 0) continue;   /* :628-631 */
-            cell_pose(cells[i].code, m_xyz, m_nrm, s_xyz, s_nrm, poses + 16 * i);
+            cell_pose(cells[i].code, frame_cache_get(&fm, ((uint32_t)cells[i].code) >> 6),
+                      frame_cache_get(&fs, (uint32_t)(cells[i].code >> 32)), poses + 16 * i);
         }
+        free(fs.idx); free(fs.T); free(fm.idx); free(fm.T);
     }
     if (cpu_clustering) {
         cluster_greedy(poses, cells, n, d_dist, POSE_D, T_out);      /* model.cu:262-263 */
