@@ -221,6 +221,7 @@ void oslam_model_destroy(oslam_model *m)
     if (m->ent.uv) (void)hipFree(m->ent.uv);
     if (m->ent.mi) (void)hipFree(m->ent.mi);
     if (m->table.ukeys) (void)hipFree(m->table.ukeys);
+    if (m->table.reach) (void)hipFree(m->table.reach);
     if (m->d_hits) (void)hipFree(m->d_hits);
     if (m->d_hit_count) (void)hipFree(m->d_hit_count);
     if (m->d_counters) (void)hipFree(m->d_counters);
@@ -300,6 +301,10 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
         HIPCHK(hipMemsetAsync(m->table.ukeys, 0, sizeof(uint32_t) * (size_t)m->table.ucap, (hipStream_t)g_stream));
         HIPCHK(hipMemsetAsync(d_small + 64, 0, sizeof(uint32_t), (hipStream_t)g_stream));
         KCHK(oslamk_union_build(m->table, d_small + 66, d_small + 64, g_stream));
+        /* which distance bins can produce a model key at all (lets the scene-key kernel drop far pairs) */
+        HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
+        HIPCHK(hipMemsetAsync(m->table.reach, 0, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), (hipStream_t)g_stream));
+        KCHK(oslamk_reach_build(m->table, m->d_dist, g_stream));
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
     HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));

@@ -56,7 +56,12 @@ typedef struct oslamk_table {
     uint32_t *ukeys;           /* [ucap] union of the keys of all slices (0 = empty) */
     uint32_t ucap;             /* power of two */
     uint32_t ushift;
+    /* reach[k1 / 32] bit k1 % 32: some key of the model can come from a pair in distance bin k1
+     * (FNV collisions included), k1 < OSLAMK_REACH_BINS; pairs in other bins cannot hit */
+    uint32_t *reach;
 } oslamk_table;
+
+#define OSLAMK_REACH_BINS 16384
 
 /* Counters one vote launch accumulates (device memory, zeroed by the host). */
 typedef struct oslamk_counters {
@@ -86,6 +91,8 @@ int oslamk_model_count(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_ta
 int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
 /* fill t.ukeys with every distinct key; *n_keys = number of distinct keys */
 int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream);
+/* fill t.reach by enumerating every key each distance bin can produce */
+int oslamk_reach_build(oslamk_table t, float d_dist, void *stream);
 /* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed). */
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
                       const float *tmg, oslamk_entries ent, void *stream);

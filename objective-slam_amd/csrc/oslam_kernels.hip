@@ -149,6 +149,28 @@ __global__ void k_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overfl
     atomicExch(overflow, 1u);
 }
 
+/* one workgroup per distance bin k1: does any of the 17^3 keys of that bin exist in the model? */
+__global__ __launch_bounds__(256) void k_reach_build(oslamk_table t, float d_dist)
+{
+    __shared__ uint32_t s_found;
+    const uint32_t k1 = blockIdx.x, mask = t.ucap - 1;
+    if (threadIdx.x == 0) s_found = 0;
+    __syncthreads();
+    for (uint32_t combo = threadIdx.x; combo < PC_ANGLE_COMBOS; combo += 256) {
+        const uint32_t key = pc_key_of_bins(k1, combo, d_dist);
+        if (key == 0) continue;
+        uint32_t slot = slot_of(key, t.ushift);
+        for (uint32_t probe = 0; probe <= mask; probe++) {
+            const uint32_t k = t.ukeys[slot];
+            if (k == key) { s_found = 1; break; }
+            if (k == 0) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_found) atomicOr(&t.reach[k1 >> 5], 1u << (k1 & 31u));
+}
+
 /* pass 2: same pairs, written into their buckets */
 __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
                              const float *tmg, oslamk_entries ent)
@@ -264,52 +286,83 @@ struct Chunk {
 };
 
 /* Scene::Scene's key pass (scene.cu:24-55: K1 ppf_kernel + K2 ppf_hash_kernel) fused with
- * the lookup of model.cu:96-97: one thread per scene pair (reference point r, point i).
- * Pairs whose key is in the model (union of all slices) are appended to r's hit list as
- * {key, (T_s_g*s_i).y, (T_s_g*s_i).z, theta_v}; one atomic per wave reserves the slots.
- * grid (ceil(S/256), refs in this batch). */
+ * the lookup of model.cu:96-97, for the pairs (reference point r, point i) of one tile of
+ * KEY_TILE scene points.  Phase 1 (cheap, every pair): distance bin only; pairs whose bin
+ * cannot produce a model key (table.reach: exact, FNV collisions included) are dropped, the
+ * rest are compacted into LDS.  Phase 2 (dense lanes): full key, union-table probe, and pairs
+ * that hit are appended to r's hit list as {key, (T_s_g*s_i).y, (T_s_g*s_i).z, theta_v}; one
+ * atomic per wave reserves the slots.  grid (ceil(S/KEY_TILE), refs in this batch). */
+#define KEY_TILE 4096
 __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 {
+    __shared__ uint32_t s_list[KEY_TILE];
+    __shared__ uint32_t s_n;
     const int ref_local = blockIdx.y;
     const int ref_ord = a.first_ref + ref_local;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
     const int S = a.scene.n;
     const uint32_t r = a.ref_idx[ref_ord];
-    bool hit = false;
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (i < S && (uint32_t)i != r) {
-        const float nrx = a.scene.nx[r], nry = a.scene.ny[r], nrz = a.scene.nz[r];
-        float x, y, z;
-        const uint32_t key = cloud_pair_key(a.scene, i, a.scene.px[r], a.scene.py[r], a.scene.pz[r],
-                                            nrx, nry, nrz, pc_norm3(nrx, nry, nrz), a.d_dist,
-                                            a.inv_d_dist, &x, &y, &z);
-        if (key != 0) {                                       /* kernel.cu:491,520 */
-            const uint32_t mask = a.table.ucap - 1;
-            uint32_t slot = slot_of(key, a.table.ushift);
-            for (uint32_t probe = 0; probe <= mask; probe++) {
-                const uint32_t k = a.table.ukeys[slot];
-                if (k == key) { hit = true; break; }
-                if (k == 0) break;
-                slot = (slot + 1) & mask;
-            }
-            if (hit) {
-                const float *rows = a.tsg + 8 * (size_t)ref_ord;
-                float vy = pc_row_dot(rows, x, y, z);         /* kernel.cu:334-336 */
-                float vz = pc_row_dot(rows + 4, x, y, z);
-                rec = make_uint4(key, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz),
-                                 pc_angle_q17(vy, vz));
-            }
+    const float prx = a.scene.px[r], pry = a.scene.py[r], prz = a.scene.pz[r];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+
+    for (int c = 0; c < KEY_TILE / 256; c++) {
+        const int i = blockIdx.x * KEY_TILE + c * 256 + threadIdx.x;
+        bool keep = false;
+        if (i < S && (uint32_t)i != r) {
+            const int k = pc_pair_dist_bin(a.scene.px[i] - prx, a.scene.py[i] - pry, a.scene.pz[i] - prz,
+                                           a.d_dist, a.inv_d_dist);
+            keep = (unsigned)k >= OSLAMK_REACH_BINS || ((a.table.reach[k >> 5] >> (k & 31)) & 1u);
+        }
+        const unsigned long long km = __ballot(keep);
+        if (km) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__popcll(km));
+            base = readlane_u(base, 0);
+            if (keep) s_list[base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = (uint32_t)i;
         }
     }
-    const unsigned long long hm = __ballot(hit);
-    if (hm) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
-        base = readlane_u(base, 0);
-        if (hit) {
-            const uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-            reinterpret_cast<uint4 *>(a.hits)[(size_t)ref_local * a.hit_stride + base + rank] = rec;
+    __syncthreads();
+
+    const uint32_t n_keep = s_n;
+    const float nrx = a.scene.nx[r], nry = a.scene.ny[r], nrz = a.scene.nz[r];
+    const float nrn = pc_norm3(nrx, nry, nrz);
+    const float *rows = a.tsg + 8 * (size_t)ref_ord;
+    for (uint32_t j0 = 0; j0 < n_keep; j0 += 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        bool hit = false;
+        uint4 rec = make_uint4(0, 0, 0, 0);
+        if (j < n_keep) {
+            const int i = (int)s_list[j];
+            float x, y, z;
+            const uint32_t key = cloud_pair_key(a.scene, i, prx, pry, prz, nrx, nry, nrz, nrn, a.d_dist,
+                                                a.inv_d_dist, &x, &y, &z);
+            if (key != 0) {                                       /* kernel.cu:491,520 */
+                const uint32_t mask = a.table.ucap - 1;
+                uint32_t slot = slot_of(key, a.table.ushift);
+                for (uint32_t probe = 0; probe <= mask; probe++) {
+                    const uint32_t k = a.table.ukeys[slot];
+                    if (k == key) { hit = true; break; }
+                    if (k == 0) break;
+                    slot = (slot + 1) & mask;
+                }
+                if (hit) {
+                    const float vy = pc_row_dot(rows, x, y, z);     /* kernel.cu:334-336 */
+                    const float vz = pc_row_dot(rows + 4, x, y, z);
+                    rec = make_uint4(key, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz),
+                                     pc_angle_q17(vy, vz));
+                }
+            }
+        }
+        const unsigned long long hm = __ballot(hit);
+        if (hm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
+            base = readlane_u(base, 0);
+            if (hit) {
+                const uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                reinterpret_cast<uint4 *>(a.hits)[(size_t)ref_local * a.hit_stride + base + rank] = rec;
+            }
         }
     }
 }
@@ -581,10 +634,16 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
     return (int)hipGetLastError();
 }
 
+int oslamk_reach_build(oslamk_table t, float d_dist, void *stream)
+{
+    hipLaunchKernelGGL(k_reach_build, dim3(OSLAMK_REACH_BINS), dim3(256), 0, (hipStream_t)stream, t, d_dist);
+    return (int)hipGetLastError();
+}
+
 int oslamk_scene_hits(const oslamk_vote_args *a, void *stream)
 {
     if (a->n_launch <= 0) return 0;
-    dim3 grid((unsigned)((a->scene.n + 255) / 256), (unsigned)a->n_launch);
+    dim3 grid((unsigned)((a->scene.n + KEY_TILE - 1) / KEY_TILE), (unsigned)a->n_launch);
     hipLaunchKernelGGL(k_scene_hits, grid, dim3(256), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }

@@ -20,10 +20,16 @@
 #include "oslam_pose.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "ppf_math.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define POSE_PI PM_PI_F
 #define POSE_D PM_D_ANGLE
@@ -222,7 +228,6 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
     hash_idx *hi = (hash_idx *)malloc(sizeof(hash_idx) * n);
     const float rot_thresh = 2 * POSE_D, rot_thresh_sq = rot_thresh * rot_thresh;
     size_t i, best = 0;
-    int dx, dy, dz;
 
     for (i = 0; i < n; i++) {
         uint32_t m = ((uint32_t)cells[i].code) >> 6;
@@ -235,45 +240,59 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
     }
     qsort(hi, n, sizeof(hash_idx), hash_idx_order);
 
-    for (i = 0; i < n; i++) {
-        const float *q = quat + 4 * i;
-        float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
-        float ox = tx, oy = ty, oz = tz;
-        float votes = 1;                                     /* kernel.cu:722 */
-        for (dx = -1; dx < 2; dx++)
-            for (dy = -1; dy < 2; dy++)
-                for (dz = -1; dz < 2; dz++) {
-                    int32_t nb[3];
-                    uint32_t h;
-                    size_t j;
-                    if (dx == 0 && dy == 0 && dz == 0) continue;   /* kernel.cu:684-689 */
-                    nb[0] = cell[3 * i] + dx; nb[1] = cell[3 * i + 1] + dy; nb[2] = cell[3 * i + 2] + dz;
-                    h = fnv_cell(nb);
-                    if (h == 0) continue;                          /* kernel.cu:727 */
-                    for (j = hash_lower_bound(hi, n, h); j < n && hi[j].hash == h; j++) {
-                        size_t o = hi[j].idx;
-                        const float *qo = quat + 4 * o;
-                        float oc = wv[o];
-                        float qd = fabsf(8 * (1 - (q[0] * qo[0] + q[1] * qo[1] + q[2] * qo[2] + q[3] * qo[3])));
-                        if (!(qd < rot_thresh_sq)) continue;
-                        if (!use_l1) {
-                            float ex = tx - trans[3 * o], ey = ty - trans[3 * o + 1], ez = tz - trans[3 * o + 2];
-                            if (!(sqrtf(ex * ex + ey * ey + ez * ez) < d_dist)) continue;
+    /* Each pose scans its 26 neighbour cells in a fixed order, so its float sums do not depend
+     * on the other poses -- unless translations are averaged in place (kernel.cu:747-758), which
+     * stays serial in index order.  Threads: at most 16 (a 1-GPU share of the host). */
+    {
+        long ii;
+        int threads = 1;
+#ifdef _OPENMP
+        threads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+        if (averaged || n < 512) threads = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
+        for (ii = 0; ii < (long)n; ii++) {
+            const size_t i = (size_t)ii;
+            const float *q = quat + 4 * i;
+            float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
+            float ox = tx, oy = ty, oz = tz;
+            float votes = 1;                                     /* kernel.cu:722 */
+            int dx, dy, dz;
+            for (dx = -1; dx < 2; dx++)
+                for (dy = -1; dy < 2; dy++)
+                    for (dz = -1; dz < 2; dz++) {
+                        int32_t nb[3];
+                        uint32_t h;
+                        size_t j;
+                        if (dx == 0 && dy == 0 && dz == 0) continue;   /* kernel.cu:684-689 */
+                        nb[0] = cell[3 * i] + dx; nb[1] = cell[3 * i + 1] + dy; nb[2] = cell[3 * i + 2] + dz;
+                        h = fnv_cell(nb);
+                        if (h == 0) continue;                          /* kernel.cu:727 */
+                        for (j = hash_lower_bound(hi, n, h); j < n && hi[j].hash == h; j++) {
+                            size_t o = hi[j].idx;
+                            const float *qo = quat + 4 * o;
+                            float oc = wv[o];
+                            float qd = fabsf(8 * (1 - (q[0] * qo[0] + q[1] * qo[1] + q[2] * qo[2] + q[3] * qo[3])));
+                            if (!(qd < rot_thresh_sq)) continue;
+                            if (!use_l1) {
+                                float ex = tx - trans[3 * o], ey = ty - trans[3 * o + 1], ez = tz - trans[3 * o + 2];
+                                if (!(sqrtf(ex * ex + ey * ey + ez * ez) < d_dist)) continue;
+                            }
+                            if (averaged) {                            /* kernel.cu:747-752 */
+                                float s;
+                                ox = votes * ox; oy = votes * oy; oz = votes * oz;
+                                ox = ox + wv[o] * trans[3 * o];
+                                oy = oy + wv[o] * trans[3 * o + 1];
+                                oz = oz + wv[o] * trans[3 * o + 2];
+                                s = 1 / (votes + oc);
+                                ox = s * ox; oy = s * oy; oz = s * oz;
+                            }
+                            votes += oc;
                         }
-                        if (averaged) {                            /* kernel.cu:747-752 */
-                            float s;
-                            ox = votes * ox; oy = votes * oy; oz = votes * oz;
-                            ox = ox + wv[o] * trans[3 * o];
-                            oy = oy + wv[o] * trans[3 * o + 1];
-                            oz = oz + wv[o] * trans[3 * o + 2];
-                            s = 1 / (votes + oc);
-                            ox = s * ox; oy = s * oy; oz = s * oz;
-                        }
-                        votes += oc;
                     }
-                }
-        score[i] = votes;
-        trans[3 * i] = ox; trans[3 * i + 1] = oy; trans[3 * i + 2] = oz;   /* kernel.cu:758 */
+            score[i] = votes;
+            if (averaged) { trans[3 * i] = ox; trans[3 * i + 1] = oy; trans[3 * i + 2] = oz; }   /* kernel.cu:758 */
+        }
     }
     for (i = 1; i < n; i++) if (score[i] > score[best]) best = i;         /* model.cu:292-295 */
     free(wv); free(score); free(cell); free(hi);
@@ -379,6 +398,13 @@ static void cluster_greedy(const float *T, const oslam_cell *cells, size_t n, fl
     free(head); free(member); free(cvotes);
 }
 
+static double pose_now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, const float *m_nrm,
                      size_t M, const float *s_xyz, const float *s_nrm, size_t S, float d_dist,
                      int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
@@ -386,6 +412,8 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
 {
     float *poses;
     size_t i;
+    const int trace = getenv("OSLAM_TRACE_POSE") != NULL;
+    double t0 = pose_now_ms(), t1, t2;
     memset(T_out, 0, 16 * sizeof(float));
     if (n == 0) return OSLAM_E_NO_VOTES;
     for (i = 0; i < n; i++) {
@@ -407,6 +435,7 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
         }
         free(fs.idx); free(fs.T); free(fm.idx); free(fm.T);
     }
+    t1 = pose_now_ms();
     if (cpu_clustering) {
         cluster_greedy(poses, cells, n, d_dist, POSE_D, T_out);      /* model.cu:262-263 */
     } else if (n > 1) {
@@ -424,6 +453,8 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
         T_out[3] = trans[3 * best]; T_out[7] = trans[3 * best + 1]; T_out[11] = trans[3 * best + 2];
         free(trans); free(quat);
     }
+    t2 = pose_now_ms();
+    if (trace) fprintf(stderr, "[oslam pose stage] %zu cells: poses %.2f ms, clustering %.2f ms\n", n, t1 - t0, t2 - t1);
     if (poses_out) memcpy(poses_out, poses, 16 * n * sizeof(float));
     free(poses);
     return OSLAM_OK;

@@ -29,6 +29,15 @@ PM_HD uint32_t pc_quant_bits(float x, float step, float inv_step)
     return PM_BITS_F2U(q);
 }
 
+/* Distance part of a pair's feature: |d| and its bin k1 = floor(|d| / d_dist) (or -1 when
+ * the quotient is NaN or >= 2^21 and the generic quantisation has to run). */
+PM_HD int pc_pair_dist_bin(float dx, float dy, float dz, float d_dist, float inv_d_dist)
+{
+    int k;
+    (void)pm_quant_down_pos(pm_sqrtf(dx * dx + dy * dy + dz * dz), d_dist, inv_d_dist, &k);
+    return k;
+}
+
 /* Key of the ordered pair (p1,n1) -> (p2,n2); 0 when the distance is not a
  * finite number (the reference maps NaN in .x to key 0, kernel.cu:467-469).
  * n1n = norm(n1) is passed in because the caller keeps it per point. */
@@ -54,6 +63,21 @@ PM_HD uint32_t pc_pair_key(float p1x, float p1y, float p1z, float n1x, float n1y
     h = pm_fnv1a_word(h, pc_quant_bits(a2, D, invD));
     h = pm_fnv1a_word(h, pc_quant_bits(a3, D, invD));
     h = pm_fnv1a_word(h, pc_quant_bits(a4, D, invD));
+    return h;
+}
+
+/* Every key a pair in distance bin k1 can have: the quantised distance is (float)k1 * d_dist
+ * and each quantised angle is one of (float)j * D, j = 0..15, or the NaN pattern -- 17^3
+ * combinations.  `combo` in [0, 4913). */
+#define PC_ANGLE_VALUES 17
+#define PC_ANGLE_COMBOS (17 * 17 * 17)
+PM_HD uint32_t pc_key_of_bins(uint32_t k1, uint32_t combo, float d_dist)
+{
+    const uint32_t j2 = combo % 17u, j3 = (combo / 17u) % 17u, j4 = combo / 289u;
+    uint32_t h = pm_fnv1a_word(PM_FNV_BASIS, PM_BITS_F2U((float)k1 * d_dist));
+    h = pm_fnv1a_word(h, j2 < 16u ? PM_BITS_F2U((float)j2 * PM_D_ANGLE) : PM_NAN_BITS);
+    h = pm_fnv1a_word(h, j3 < 16u ? PM_BITS_F2U((float)j3 * PM_D_ANGLE) : PM_NAN_BITS);
+    h = pm_fnv1a_word(h, j4 < 16u ? PM_BITS_F2U((float)j4 * PM_D_ANGLE) : PM_NAN_BITS);
     return h;
 }
 
