@@ -190,11 +190,16 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
         if (tab[slot].key == key) break;
         slot = (slot + 1) & mask;
     }
-    uint32_t pos = atomicAdd(&tab[slot].cur, 1u);
+    uint32_t pos = atomicAdd(&tab[slot].cur, 1u) & 0x7fffffffu;   /* bit 31 is the marker flag */
     size_t e = (size_t)tab[slot].start + pos;
     const float *rows = tmg + 8 * (size_t)m_r;
     float uy = pc_row_dot(rows, x, y, z), uz = pc_row_dot(rows + 4, x, y, z);
-    ent.e4[e] = ((uint32_t)(m_r - slice * OSLAMK_SLICE) << 22) | pc_angle_q17(uy, uz);
+    {
+        const uint32_t th = pc_angle_q17(uy, uz);
+        /* a marker forces the whole bucket through the exact path: flagged in bit 31 of the cursor */
+        if (th == PC_Q17_FORCE) atomicOr(&tab[slot].cur, 0x80000000u);
+        ent.e4[e] = ((uint32_t)(m_r - slice * OSLAMK_SLICE) << 22) | (th == PC_Q17_FORCE ? 0u : th);
+    }
     ent.mi[e] = (uint16_t)i;
     if (ent.uv) {
         oslamk_uv en;
@@ -237,16 +242,50 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
 
 /* which chunk of which bucket (wave-uniform) */
 struct ChunkDesc {
-    uint32_t st, off, ln, cs;
+    uint32_t st, off, ln, cs2;
     float vy, vz;
-    bool valid;
+    bool valid, forced;
 };
 
 /* A chunk of VOTE_U x 256 model-pair entries held in registers by one wave: lane l holds
  * entries 4*(u*64 + l) .. +3 of the chunk (one 16-byte load each).
  * A vote: theta_v - theta_u in units of 2^-17 bin gives bin and position in the bin; only
  * positions within 2^-12 bin of an edge (0.05 % of votes) are re-evaluated with the reference's
- * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's. */
+ * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's.
+ * The code is straight-line: lanes past the end of the bucket add into a per-lane trash word
+ * behind the accumulator instead of branching around the atomic. */
+#define ACC_TRASH ACC_CELLS            /* 64 words, one per lane */
+
+/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table:
+ * {entry index, local model reference, v.y, v.z}. */
+struct SlowQueue {
+    static constexpr uint32_t CAP = 96;
+    uint4 *q;
+    uint32_t n;                        /* wave-uniform */
+    __device__ __forceinline__ void push(unsigned long long mask, bool mine, int lane, uint32_t entry,
+                                         uint32_t mr, float vy, float vz)
+    {
+        if (mine) {
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            q[n + rank] = make_uint4(entry, mr, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz));
+        }
+        n += (uint32_t)__popcll(mask);
+    }
+    __device__ __forceinline__ void flush(const oslamk_vote_args &a, uint32_t *acc, const uint32_t *tbl, int lane)
+    {
+        for (uint32_t base = 0; base < n; base += WAVE) {
+            if (base + lane < n) {
+                const uint4 it = q[base + lane];
+                const float2 uv = *reinterpret_cast<const float2 *>(&a.ent.uv[it.x]);
+                const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, __builtin_bit_cast(float, it.z),
+                                                        __builtin_bit_cast(float, it.w), tbl);
+                if (bin < OSLAMK_NBIN) atomicAdd(&acc[(it.y << 5) + bin], 1u);
+            }
+        }
+        n = 0;
+    }
+};
+
 template <int MODE>
 struct Chunk {
     static constexpr int U = VOTE_U;
@@ -260,27 +299,43 @@ struct Chunk {
             if (e < ln) v[u] = *reinterpret_cast<const uint4 *>(&a.ent.e4[(size_t)st + e]);
         }
     }
+    /* cs2 = (theta_v + 15 bins) mod one turn.  Votes that need the reference's float sequence
+     * are not evaluated here (their operands are a dependent gather that would stall the
+     * stream): they are queued per wave and evaluated 64 at a time by SlowQueue::flush. */
     __device__ __forceinline__ void vote(const oslamk_vote_args &a, uint32_t *acc, const uint32_t *tbl,
-                                         uint32_t st, uint32_t off, uint32_t ln, int lane, uint32_t cs,
-                                         float vy, float vz) const
+                                         SlowQueue &sq, uint32_t st, uint32_t off, uint32_t ln, int lane,
+                                         uint32_t cs2, bool forced, float vy, float vz) const
     {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t e = off + 4u * (u * WAVE + lane);
+            const int rem = (int)ln - (int)e;                /* entries of this lane that exist */
             const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            uint32_t idx[4];
+            bool need[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (e + j < ln) {
-                    const uint32_t am = w[j] & 0x3fffffu, mr = w[j] >> 22;
-                    const uint32_t t = pc_turn_q17(cs, am);
-                    unsigned bin = t >> 17;
-                    if (MODE == 0 && pc_turn_needs_exact(t, cs, am)) {
-                        const float2 uv = *reinterpret_cast<const float2 *>(&a.ent.uv[(size_t)st + e + j]);
-                        bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, tbl);
+                uint32_t t = cs2 - (w[j] & 0x3fffffu);       /* in (-turn, turn) */
+                const uint32_t t_wrapped = t + PC_Q17_TURN;
+                t = t < t_wrapped ? t : t_wrapped;           /* unsigned min = mod one turn */
+                idx[j] = rem > j ? ((w[j] >> 22) << 5) + (t >> 17) : ACC_TRASH + (uint32_t)lane;
+                /* within PC_Q17_MARGIN of a bin edge (either side)?  forced: every vote of the bucket */
+                need[j] = MODE == 0 && rem > j &&
+                          (forced || ((t - PC_Q17_MARGIN) & (PC_Q17_ONE - 1u)) >= PC_Q17_ONE - 2u * PC_Q17_MARGIN);
+            }
+            if (MODE == 0 && __any(need[0] || need[1] || need[2] || need[3])) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned long long nm = __ballot(need[j]);
+                    if (nm) {
+                        sq.push(nm, need[j], lane, st + e + j, w[j] >> 22, vy, vz);
+                        if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, acc, tbl, lane);
+                        if (need[j]) idx[j] = ACC_TRASH + (uint32_t)lane;
                     }
-                    if (bin < OSLAMK_NBIN) atomicAdd(&acc[mr * OSLAMK_NBIN + bin], 1u);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) atomicAdd(&acc[idx[j]], 1u);
         }
     }
 };
@@ -375,12 +430,13 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 template <int MODE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 {
-    __shared__ uint32_t acc[ACC_CELLS];
+    __shared__ uint32_t acc[ACC_CELLS + WAVE];      /* + one trash word per lane */
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
     __shared__ unsigned long long s_wave64[2][VOTE_THREADS / WAVE];
     __shared__ uint32_t s_g, s_lmax, s_base;
     __shared__ uint32_t s_tbl[32];
+    __shared__ uint4 s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SlowQueue::CAP : 1];
 
     typedef Chunk<MODE> CH;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
@@ -399,6 +455,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
     const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
     unsigned long long my_hits = 0, my_votes = 0;
+    SlowQueue sq;
+    sq.q = s_slow + (MODE == 0 ? wid * SlowQueue::CAP : 0);
+    sq.n = 0;
     __syncthreads();
 
     for (uint32_t base = 0; base < n_hits; base += VOTE_THREADS) {
@@ -414,6 +473,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                     start = sv.y;
                     len = sv.z;
                     my_votes += len;
+                    if (sv.w >> 31) cs = PC_Q17_FORCE;       /* the bucket holds an entry with the marker */
                     break;
                 }
                 if (sv.x == 0) break;
@@ -421,7 +481,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             }
             vy = __builtin_bit_cast(float, rec.y);
             vz = __builtin_bit_cast(float, rec.z);
-            cs = rec.w;
+            if (cs != PC_Q17_FORCE) cs = rec.w;
             if (slice == 0) my_hits += 1;
         }
         /* wave-cooperative sweep: all 64 lanes stream one bucket at a time, in chunks of
@@ -429,13 +489,18 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
          * flight while the current chunk votes */
         /* chunk generator over this wave's hit buckets (all state wave-uniform) */
         unsigned long long todo = __ballot(len > 0);
+        auto set_cs = [](ChunkDesc &d, uint32_t csq) {
+            uint32_t c = csq + 15u * PC_Q17_ONE;
+            d.forced = csq == PC_Q17_FORCE;
+            d.cs2 = c >= PC_Q17_TURN ? c - PC_Q17_TURN : c;
+        };
         ChunkDesc g;                       /* the next chunk to hand out */
         g.valid = todo != 0;
         if (g.valid) {
             const int l = __ffsll((long long)todo) - 1;
             g.st = readlane_u(start, l);
             g.ln = readlane_u(len, l);
-            g.cs = readlane_u(cs, l);
+            set_cs(g, readlane_u(cs, l));
             g.vy = readlane_f(vy, l);
             g.vz = readlane_f(vz, l);
             g.off = 0;
@@ -450,7 +515,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                         const int l = __ffsll((long long)todo) - 1;
                         g.st = readlane_u(start, l);
                         g.ln = readlane_u(len, l);
-                        g.cs = readlane_u(cs, l);
+                        set_cs(g, readlane_u(cs, l));
                         g.vy = readlane_f(vy, l);
                         g.vz = readlane_f(vz, l);
                         g.off = 0;
@@ -480,9 +545,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             d[VOTE_PIPE - 1] = next_chunk();
             if (d[VOTE_PIPE - 1].valid)
                 c[VOTE_PIPE - 1].load(a, d[VOTE_PIPE - 1].st, d[VOTE_PIPE - 1].off, d[VOTE_PIPE - 1].ln, lane);
-            cur.vote(a, acc, s_tbl, dc.st, dc.off, dc.ln, lane, dc.cs, dc.vy, dc.vz);
+            cur.vote(a, acc, s_tbl, sq, dc.st, dc.off, dc.ln, lane, dc.cs2, dc.forced, dc.vy, dc.vz);
         }
     }
+    if (MODE == 0) sq.flush(a, acc, s_tbl, lane);
     __syncthreads();
 
     /* ---- peak extraction: local max, non-empty cells, emission ---- */

@@ -289,3 +289,21 @@ def test_cpp_adaptor_runs(ppf, built_lib):
     t = [float(x) for x in r.stdout.split("=")[1].split()]
     # the scene is the model shifted by (2, -1, 0); bin-accurate recovery (d_dist = 0.05)
     assert abs(t[0] - 2.0) < 0.3 and abs(t[1] + 1.0) < 0.3 and abs(t[2]) < 0.3
+
+
+def test_accumulator_with_marker_paths(ppf, oracle, built_lib, synth):
+    """Coordinates of magnitude 2^45: every stored angle carries the 'always re-evaluate' marker
+    (ppf_core.h: vectors outside 2^-40..2^40), so all votes take the queued exact path; and a
+    tiny cloud (2^-45) for the other side of the range."""
+    for scale in (2.0 ** 45, 2.0 ** -45):
+        c = make_case(synth, 90, 200, 2040)
+        mp, sp = (c["mp"] * np.float32(scale)), (c["sp"] * np.float32(scale))
+        d = float(np.float32(c["d"]) * np.float32(scale))
+        sc = ppf.Scene(sp, c["sn"], d_dist=d)
+        mo = ppf.Model(mp, c["mn"], d_dist=d)
+        for r in (0, 57, 199):
+            assert np.array_equal(mo.vote_accumulator(sc, r),
+                                  oracle.accumulator_for_ref(mp, c["mn"], sp, c["sn"], r, d)), (scale, r)
+        mo.ppf_lookup(sc, allow_no_votes=True)
+        ocells, _ = oracle.votes_fused(mp, c["mn"], sp, c["sn"], 1, d, 0.4)
+        assert cells_equal(mo.last_cells()[0], ocells)
