@@ -178,6 +178,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_vote", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(args, M, S, df),
+                         "traffic_note": "HBM-side bytes per vote-kernel launch (rocprofv3 PMC, profiles/); below the "
+                                         "algorithmic bytes because a model-pair entry is packed into 4 bytes",
                          "alg_bytes_per_launch": per_launch_bytes, "launch_ms": per_launch_ms,
                          "launches_per_step": launches / args.steps,
                          "key_kernel_ms_per_step": ms_key_kernel / args.steps,
