@@ -129,6 +129,15 @@ int oslam_ppf_registration(const float *const *scene_xyz, const float *const *sc
 /* ht_dist (include/linalg.h:7, src/cuda/linalg.cu:9-20): out = {|dt|, |angle|}. */
 int oslam_ht_dist(const float A[16], const float B[16], float out[2]);
 
+/* voxelGridDownsample (src/alignment.cpp:79-87, applied to scenes with leaf = scene_leaf_size
+ * and to models with leaf = d_dist, :265-288; pcl/voxel_grid/voxel_grid.cpp:18-21): one output
+ * point per occupied voxel = mean of the points (and of their normals, not renormalised) in
+ * it, in ascending voxel index -- pcl::VoxelGrid's algorithm with the point order inside a
+ * voxel fixed to the input order.  xyz_out / nrm_out: packed float[cap][3]; *n_out receives the
+ * number of voxels (OSLAM_E_LIMIT if it exceeds cap or the voxel count overflows int32). */
+int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride_bytes, float leaf,
+                     int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out);
+
 /* ---- host stage (no GPU needed): accumulator peaks -> poses -> clustering.
  * Counterparts: trans_calc_kernel2, vote_weight_kernel, mat2transquat_kernel,
  * trans2idx_kernel, rot_clustering_kernel (src/cuda/kernel.cu:605-782),

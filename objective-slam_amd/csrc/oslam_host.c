@@ -211,6 +211,44 @@ done:
 }
 
 /* ------------------------------------------------------------------------ */
+int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride_bytes, float leaf,
+                     int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out)
+{
+    int rc = OSLAM_OK, k, devsel;
+    cloud_buf c;
+    float *d_out = NULL, *h_out = NULL;
+    uint32_t nv = 0;
+    size_t i;
+    memset(&c, 0, sizeof c);
+    if (!xyz || !nrm || !xyz_out || !nrm_out || !n_out || stride_bytes < 12 || !(leaf > 0.0f) || n == 0 ||
+        n > 0x7fffffffu)
+        return fail(OSLAM_E_INVALID, "bad voxel grid arguments");
+    *n_out = 0;
+    rc = pick_device(dev, &devsel);
+    if (rc != OSLAM_OK) return rc;
+    rc = cloud_upload(&c, xyz, nrm, n, stride_bytes);
+    if (rc != OSLAM_OK) return rc;
+    HIPCHK(hipMalloc((void **)&d_out, sizeof(float) * 6 * n));
+    k = oslamk_voxel_grid(c.k, leaf, d_out, &nv, g_stream);
+    if (k == -1) { rc = fail(OSLAM_E_LIMIT, "leaf size too small for the cloud extent (voxel count overflows int32)"); goto done; }
+    if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
+    if (nv > cap) { rc = fail(OSLAM_E_LIMIT, "output capacity too small"); goto done; }
+    h_out = (float *)malloc(sizeof(float) * 6 * (nv ? nv : 1));
+    if (!h_out) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    if (nv) HIPCHK(hipMemcpy(h_out, d_out, sizeof(float) * 6 * nv, hipMemcpyDeviceToHost));
+    for (i = 0; i < nv; i++) {
+        memcpy(xyz_out + 3 * i, h_out + 6 * i, 3 * sizeof(float));
+        memcpy(nrm_out + 3 * i, h_out + 6 * i + 3, 3 * sizeof(float));
+    }
+    *n_out = nv;
+done:
+    free(h_out);
+    if (d_out) (void)hipFree(d_out);
+    cloud_free(&c);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
 void oslam_model_destroy(oslam_model *m)
 {
     if (!m) return;

@@ -132,6 +132,10 @@ int oslamk_scene_hits(const oslamk_vote_args *a, void *stream);
 /* votes of the same batch (needs the hit lists) */
 int oslamk_vote(const oslamk_vote_args *a, void *stream);
 
+/* voxel grid (oslam_voxel.hip): out6 = device [n][6] (x y z nx ny nz per voxel); returns a
+ * hipError_t, or -1 when the voxel count overflows int32 */
+int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32_t *n_out, void *stream);
+
 /* device self-test: out_acos[i] = pm_acosf(x[i]); out_atan2[i] = pm_atan2f(y[i], x2[i]);
  * out_bin[i] = pc_alpha_bin_exact(...) */
 int oslamk_selftest(const float *x, const float *y, const float *x2, size_t n, float *out_acos,

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "oslam_align": (_i, [_vp, _vp, _vp, C.POINTER(Stats)]),
     "oslam_ppf_registration": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _u, _f, _i, _i, _i, _i, _vp, _vp]),
     "oslam_ht_dist": (_i, [_vp, _vp, _vp]),
+    "oslam_voxel_grid": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_build_T_g": (None, [_vp, _vp, _vp]),
     "oslam_sort_cells": (None, [_vp, _sz]),
     "oslam_filter_cells": (_sz, [_vp, _sz, _f, C.c_uint32]),
@@ -303,6 +304,15 @@ def ppf_registration(scene_clouds, model_clouds, model_d_dists, ref_point_downsa
                                     int(cpu_clustering), int(use_l1_norm), int(use_averaged_clusters),
                                     int(devUse), None, _p(out)))
     return out
+
+
+def voxel_grid(points, normals=None, leaf=None, dev=0):
+    """voxelGridDownsample (alignment.cpp:79-87): (points, normals) of the occupied voxels."""
+    xyz, nrm, n, stride, keep = _cloud_args(points, normals)
+    po, no = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    k = C.c_size_t(0)
+    _check(lib().oslam_voxel_grid(xyz, nrm, n, stride, float(leaf), int(dev), _p(po), _p(no), n, C.byref(k)))
+    return po[: k.value].copy(), no[: k.value].copy()
 
 
 def ht_dist(A, B):

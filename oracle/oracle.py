@@ -38,8 +38,8 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = os.path.join(_HERE, "liboracle_ppf.so")
-    src = os.path.join(_HERE, "oracle_ppf.c")
-    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_ppf.c", "oracle_voxel.c", "oracle_ppf.h")]
+    if not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
         build()
     L = C.CDLL(path)
     fp, u32p, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
@@ -72,6 +72,8 @@ def lib():
     L.orc_cluster_poses_cpu.restype = C.c_int
     L.orc_cluster_poses_cpu.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp]
     L.orc_ht_dist.argtypes = [vp, vp, vp]
+    L.orc_voxel_grid.restype = C.c_long
+    L.orc_voxel_grid.argtypes = [vp, vp, C.c_size_t, C.c_float, vp, vp]
     L.orc_pose_from_cells.restype = C.c_int
     L.orc_pose_from_cells.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int,
                                       C.c_int, vp]
@@ -239,6 +241,16 @@ def mat2transquat(T):
     qu = np.zeros((len(T), 4), np.float32)
     lib().orc_mat2transquat(_p(T), len(T), _p(tr), _p(qu))
     return tr, qu
+
+
+def voxel_grid(points, normals, leaf):
+    """pcl::VoxelGrid as the reference applies it (alignment.cpp:79-87); parity unpinned."""
+    p, n = _c32(points), _c32(normals)
+    po, no = np.zeros_like(p), np.zeros_like(n)
+    k = lib().orc_voxel_grid(_p(p), _p(n), len(p), float(leaf), _p(po), _p(no))
+    if k < 0:
+        raise ValueError("leaf size too small for the cloud extent")
+    return po[:k].copy(), no[:k].copy()
 
 
 def ht_dist(A, B):

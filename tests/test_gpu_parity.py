@@ -336,3 +336,29 @@ def test_baseline_config2_model_database(ppf, oracle, built_lib, synth):
     ocells, _ = oracle.votes_fused(models[1][0], models[1][1], sp, sn, 4, dd[1], 0.4)
     rc, To = oracle.pose_from_cells(ocells, models[1][0], models[1][1], sp, sn, dd[1])
     assert np.array_equal(res[0, 1], To)
+
+
+def test_voxel_grid_equals_oracle_statement(ppf, oracle, built_lib, synth):
+    """voxelGridDownsample (alignment.cpp:79-87).  PCL is not available, so parity with PCL is
+    unpinned; the GPU stage must equal the oracle's statement of PCL's algorithm exactly."""
+    mp, mn = synth.make_model(0, 30000)
+    sp, sn, _ = synth.make_scene([0], 60000, 2060, instance_points=8000, noise_sigma=0.002)
+    for pts, nrm, leaf in ((mp, mn, 0.05), (mp, mn, 0.19), (sp, sn, 0.25), (sp, sn, 3.0)):
+        go, gn = ppf.voxel_grid(pts, nrm, leaf=leaf)
+        oo, on = oracle.voxel_grid(pts, nrm, leaf)
+        assert len(go) == len(oo) and 0 < len(go) <= len(pts)
+        assert np.array_equal(go, oo) and np.array_equal(gn, on)
+    # non-finite points are ignored; a leaf that makes the voxel count overflow int32 is an error
+    bad = mp.copy()
+    bad[5] = np.nan
+    go, gn = ppf.voxel_grid(bad, mn, leaf=0.1)
+    oo, on = oracle.voxel_grid(bad, mn, 0.1)
+    assert np.array_equal(go, oo) and np.array_equal(gn, on)
+    with pytest.raises(ppf.OslamError):
+        ppf.voxel_grid(sp, sn, leaf=1e-5)
+    # the reference's pipeline: model voxel-gridded at leaf = d_dist, then registered
+    d = synth.d_dist_for(mp, 0.05)
+    mg, mgn = ppf.voxel_grid(mp, mn, leaf=d)
+    sg, sgn = ppf.voxel_grid(sp, sn, leaf=0.5 * d)
+    T = ppf.Model(mg, mgn, d_dist=d).ppf_lookup(ppf.Scene(sg, sgn, d_dist=d, ref_point_downsample_factor=5))
+    assert T.shape == (4, 4)
