@@ -138,6 +138,14 @@ int oslam_ht_dist(const float A[16], const float B[16], float out[2]);
 int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride_bytes, float leaf,
                      int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out);
 
+/* PLY clouds with normals (host only): pcl::io::loadPLYFile<pcl::PointNormal>
+ * (src/alignment.cpp:212,241) / pcl::PLYWriter (pcl/voxel_grid/voxel_grid.cpp:27-29).
+ * Reads ascii and binary_little_endian; needs x y z and nx ny nz (or normal_x normal_y
+ * normal_z).  *xyz_out, *nrm_out: malloc'd packed float[n][3], release with oslam_free. */
+int oslam_ply_read(const char *path, float **xyz_out, float **nrm_out, size_t *n_out);
+int oslam_ply_write(const char *path, const float *xyz, const float *nrm, size_t n, int binary);
+void oslam_free(void *p);
+
 /* ---- host stage (no GPU needed): accumulator peaks -> poses -> clustering.
  * Counterparts: trans_calc_kernel2, vote_weight_kernel, mat2transquat_kernel,
  * trans2idx_kernel, rot_clustering_kernel (src/cuda/kernel.cu:605-782),

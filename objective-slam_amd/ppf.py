@@ -62,6 +62,9 @@ _SIGNATURES = {
     "oslam_align": (_i, [_vp, _vp, _vp, C.POINTER(Stats)]),
     "oslam_ppf_registration": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _u, _f, _i, _i, _i, _i, _vp, _vp]),
     "oslam_ht_dist": (_i, [_vp, _vp, _vp]),
+    "oslam_ply_read": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
+    "oslam_ply_write": (_i, [C.c_char_p, _vp, _vp, _sz, _i]),
+    "oslam_free": (None, [_vp]),
     "oslam_voxel_grid": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_build_T_g": (None, [_vp, _vp, _vp]),
     "oslam_sort_cells": (None, [_vp, _sz]),
@@ -304,6 +307,31 @@ def ppf_registration(scene_clouds, model_clouds, model_d_dists, ref_point_downsa
                                     int(cpu_clustering), int(use_l1_norm), int(use_averaged_clusters),
                                     int(devUse), None, _p(out)))
     return out
+
+
+def ply_read(path):
+    """(points [n,3], normals [n,3]) of a PLY file (pcl::io::loadPLYFile<PointNormal>)."""
+    L = lib()
+    px, pn, n = C.c_void_p(0), C.c_void_p(0), C.c_size_t(0)
+    rc = L.oslam_ply_read(os.fsencode(path), C.byref(px), C.byref(pn), C.byref(n))
+    if rc != OSLAM_OK:
+        raise OslamError(rc, "cannot read PLY file %s" % path)
+    try:
+        shape = (n.value, 3)
+        pts = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), shape=shape).copy() if n.value else np.zeros(shape, np.float32)
+        nrm = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_float)), shape=shape).copy() if n.value else np.zeros(shape, np.float32)
+    finally:
+        L.oslam_free(px)
+        L.oslam_free(pn)
+    return pts, nrm
+
+
+def ply_write(path, points, normals, binary=True):
+    p = np.ascontiguousarray(points, np.float32)
+    q = np.ascontiguousarray(normals, np.float32)
+    rc = lib().oslam_ply_write(os.fsencode(path), _p(p), _p(q), len(p), int(binary))
+    if rc != OSLAM_OK:
+        raise OslamError(rc, "cannot write PLY file %s" % path)
 
 
 def voxel_grid(points, normals=None, leaf=None, dev=0):
