@@ -125,10 +125,6 @@ struct oslam_model {
     uint64_t num_model_keys;
     float *weights;
     /* align workspace */
-    oslamk_hit *d_hits;               /* per-reference hit lists of one batch */
-    size_t hits_bytes;
-    uint32_t *d_hit_count;
-    size_t hit_count_cap;
     oslamk_counters *d_counters;
     oslamk_cell *d_out;
     uint32_t out_cap;
@@ -260,8 +256,6 @@ void oslam_model_destroy(oslam_model *m)
     if (m->ent.mi) (void)hipFree(m->ent.mi);
     if (m->table.ukeys) (void)hipFree(m->table.ukeys);
     if (m->table.reach) (void)hipFree(m->table.reach);
-    if (m->d_hits) (void)hipFree(m->d_hits);
-    if (m->d_hit_count) (void)hipFree(m->d_hit_count);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
     free(m->h_out);
@@ -457,35 +451,50 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
     return OSLAM_OK;
 }
 
-/* scratch for the hit lists: up to 8 GiB, at least one reference point's worth */
-static int ensure_hit_scratch(oslam_model *m, const oslam_scene *s, int *batch_out)
+/* Scratch for the hit lists of one batch of reference points: one pool per device, shared by all
+ * models (it is only live inside an align call; like the reference, calls on one device are not
+ * re-entrant).  Up to OSLAM_SCRATCH_GIB (default 8) GiB, at least one reference point's worth. */
+#define MAX_DEVICES 64
+typedef struct {
+    oslamk_hit *hits;
+    size_t hits_bytes;
+    uint32_t *hit_count;
+    size_t hit_count_cap;
+} scratch_pool;
+static scratch_pool g_pool[MAX_DEVICES];
+
+static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratch_pool **pool_out, int *batch_out)
 {
     int rc = OSLAM_OK;
     const size_t per_ref = (size_t)s->c.n * sizeof(oslamk_hit);
     size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)8 << 30;
+    const char *env = getenv("OSLAM_SCRATCH_GIB");
+    scratch_pool *p;
     size_t batch;
+    if (m->dev < 0 || m->dev >= MAX_DEVICES) return fail(OSLAM_E_LIMIT, "device ordinal too large");
+    p = &g_pool[m->dev];
+    if (env && atoi(env) > 0) cap = (size_t)atoi(env) << 30;
     if (want > cap) want = cap;
     if (want < per_ref) want = per_ref;
-    if (m->hits_bytes < want) {
-        if (m->d_hits) { (void)hipFree(m->d_hits); m->d_hits = NULL; m->hits_bytes = 0; }
-        HIPCHK(hipMalloc((void **)&m->d_hits, want));
-        m->hits_bytes = want;
+    if (p->hits_bytes < want) {
+        if (p->hits) { (void)hipFree(p->hits); p->hits = NULL; p->hits_bytes = 0; }
+        HIPCHK(hipMalloc((void **)&p->hits, want));
+        p->hits_bytes = want;
     }
-    batch = m->hits_bytes / per_ref;
+    batch = p->hits_bytes / per_ref;
     if (batch > (size_t)s->n_ref) batch = (size_t)(s->n_ref > 0 ? s->n_ref : 1);
     if (batch > 65535) batch = 65535;            /* grid.y of the scene-key kernel */
-    if (m->hit_count_cap < batch) {
-        if (m->d_hit_count) { (void)hipFree(m->d_hit_count); m->d_hit_count = NULL; m->hit_count_cap = 0; }
-        HIPCHK(hipMalloc((void **)&m->d_hit_count, sizeof(uint32_t) * batch));
-        m->hit_count_cap = batch;
+    if (p->hit_count_cap < batch) {
+        if (p->hit_count) { (void)hipFree(p->hit_count); p->hit_count = NULL; p->hit_count_cap = 0; }
+        HIPCHK(hipMalloc((void **)&p->hit_count, sizeof(uint32_t) * batch));
+        p->hit_count_cap = batch;
     }
+    *pool_out = p;
     *batch_out = (int)batch;
 done:
     return rc;
 }
 
-/* scene keys + votes over the scene's shard, in batches of reference points; leaves emitted
- * cells in m->d_out */
 #define MAX_BATCH_EVENTS 64
 
 static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
@@ -495,8 +504,9 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     hipEvent_t e0 = NULL, e1 = NULL, ev[3 * MAX_BATCH_EVENTS];
     oslamk_vote_args a;
     hipStream_t st = (hipStream_t)g_stream;
+    scratch_pool *pool = NULL;
     memset(ev, 0, sizeof ev);
-    rc = ensure_hit_scratch(m, s, &batch);
+    rc = ensure_hit_scratch(m, s, &pool, &batch);
     if (rc != OSLAM_OK) return rc;
     memset(&a, 0, sizeof a);
     a.scene = s->c.k;
@@ -515,8 +525,8 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.acc_dump = NULL;
     a.dump_ref = -1;
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
-    a.hits = m->d_hits;
-    a.hit_count = m->d_hit_count;
+    a.hits = pool->hits;
+    a.hit_count = pool->hit_count;
     a.hit_stride = (size_t)s->c.n;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -526,7 +536,7 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
         const int timed = nb < MAX_BATCH_EVENTS;
         a.first_ref = first;
         a.n_launch = s->n_ref - first < batch ? s->n_ref - first : batch;
-        HIPCHK(hipMemsetAsync(m->d_hit_count, 0, sizeof(uint32_t) * (size_t)a.n_launch, st));
+        HIPCHK(hipMemsetAsync(pool->hit_count, 0, sizeof(uint32_t) * (size_t)a.n_launch, st));
         if (timed) {
             for (i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ev[3 * nb + i]));
             HIPCHK(hipEventRecord(ev[3 * nb], st));
@@ -850,13 +860,14 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
     {
         int batch = 1;
-        rc = ensure_hit_scratch(m, s, &batch);
+        scratch_pool *pool = NULL;
+        rc = ensure_hit_scratch(m, s, &pool, &batch);
         if (rc != OSLAM_OK) goto done;
+        a.hits = pool->hits;
+        a.hit_count = pool->hit_count;
     }
-    a.hits = m->d_hits;
-    a.hit_count = m->d_hit_count;
     a.hit_stride = (size_t)s->c.n;
-    HIPCHK(hipMemsetAsync(m->d_hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));
+    HIPCHK(hipMemsetAsync(a.hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));
     KCHK(oslamk_scene_hits(&a, g_stream));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), (hipStream_t)g_stream));
     KCHK(oslamk_vote(&a, g_stream));
