@@ -390,3 +390,38 @@ def test_cli_front_end(ppf, built_lib, synth, tmp_path):
     lines = r.stderr.split("Found transformation")[1].splitlines()[1:5]
     Tcli = np.array([[float(x) for x in ln.split()] for ln in lines], np.float32)
     np.testing.assert_allclose(Tcli, T, atol=2e-6)
+
+
+def test_random_small_clouds_match_oracle(ppf, oracle, built_lib):
+    """Seeded sweep over ragged sizes (down to 2 points), tau_d, df, normals that are not unit
+    length, duplicated points and planar patches: peak cells, counters and pose against the oracle."""
+    rng = np.random.default_rng(20260)
+    for trial in range(24):
+        M = int(rng.choice([2, 3, 5, 17, 64, 130, 333, 1025, 1100]))
+        S = int(rng.choice([2, 3, 9, 65, 257, 700, 1024, 1500]))
+        df = int(rng.choice([1, 1, 2, 7]))
+        mp = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+        mn = (rng.normal(size=(M, 3)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        k = min(M, S)
+        sp = rng.uniform(-2, 2, (S, 3)).astype(np.float32)
+        sn = rng.normal(size=(S, 3)).astype(np.float32)
+        sp[:k] = (mp[:k] @ R.T + rng.uniform(-1, 1, 3)).astype(np.float32)      # part of the model, moved
+        sn[:k] = (mn[:k] @ R.T).astype(np.float32)
+        if S > 20:
+            sp[k // 2] = sp[0]                                                   # duplicate point
+            sp[-8:, 2] = 0.5                                                     # planar patch, equal normals
+            sn[-8:] = np.float32([0, 0, 2])
+        d = float(np.float32(rng.choice([0.05, 0.11, 0.3]) * 2.0))
+        par = ppf.default_params()
+        sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df, params=par)
+        mo = ppf.Model(mp, mn, d_dist=d, params=par)
+        T = mo.ppf_lookup(sc, allow_no_votes=True)
+        ocells, ost = oracle.votes_fused(mp, mn, sp, sn, df, d, 0.4)
+        cells = mo.last_cells()[0]
+        assert cells_equal(cells, ocells), (trial, M, S, df, d)
+        for key in ("num_scene_ppfs", "num_hits", "num_votes", "num_unique_votes", "max_count"):
+            assert mo.stats[key] == ost[key], (trial, key)
+        if len(ocells):
+            rc, To = oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)
+            assert np.array_equal(T, To), (trial, M, S)
