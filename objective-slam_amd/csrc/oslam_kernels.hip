@@ -6,14 +6,18 @@
  * What the reference does with N^2-sized arrays and Thrust sorts
  * (pcl/alignment/src/cuda/{scene,model}.cu) is fused here:
  *   model build : pair key -> per-slice open-addressing table -> bucketed
- *                 16-byte pair entries (two counting passes, no sort);
- *   scene keys  : one thread per scene pair (reference r, point i): key ->
- *                 probe of the union table of all model keys -> per-reference
- *                 hit list (key, T_s_g*s_i) written by wave-aggregated appends;
+ *                 4-byte pair entries (two counting passes, no sort); union table
+ *                 of all keys; bitset of the distance bins that can reach a key;
+ *   scene keys  : per (reference r, tile of scene points): distance bin of every
+ *                 pair, unreachable bins dropped, the rest compacted in LDS; full
+ *                 key -> union-table probe -> per-reference hit list
+ *                 {key, T_s_g*s_i, theta_v} written by wave-aggregated appends;
  *   voting      : one workgroup per (scene reference point, model slice):
  *                 hit -> slice table probe -> wave-cooperative, prefetched sweep
- *                 of the bucket -> LDS accumulator [1024 model refs][32 alpha
- *                 bins] -> in-kernel peak extraction.
+ *                 of the bucket (16 bytes = 4 entries per lane) -> integer alpha
+ *                 bin -> LDS accumulator [1024 model refs][32 alpha bins]; votes
+ *                 near a bin edge queued and re-evaluated with the reference's
+ *                 float sequence; in-kernel peak extraction.
  */
 #include <hip/hip_runtime.h>
 
@@ -248,7 +252,7 @@ struct ChunkDesc {
 };
 
 /* A chunk of VOTE_U x 256 model-pair entries held in registers by one wave: lane l holds
- * entries 4*(u*64 + l) .. +3 of the chunk (one 16-byte load each).
+ * entries 4*(u*64 + l) .. +3 of the chunk (one 16-byte load each; VOTE_U = 1 measured best).
  * A vote: theta_v - theta_u in units of 2^-17 bin gives bin and position in the bin; only
  * positions within 2^-12 bin of an edge (0.05 % of votes) are re-evaluated with the reference's
  * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's.
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             if (slice == 0) my_hits += 1;
         }
         /* wave-cooperative sweep: all 64 lanes stream one bucket at a time, in chunks of
-         * CH::U x 64 entries; the next chunk's loads (possibly of the next bucket) are in
+         * CH::U x 256 entries; the next chunk's loads (possibly of the next bucket) are in
          * flight while the current chunk votes */
         /* chunk generator over this wave's hit buckets (all state wave-uniform) */
         unsigned long long todo = __ballot(len > 0);
