@@ -604,6 +604,43 @@ done:
     return rc;
 }
 
+/* clustering scores on the bound device (see oslam_pose.h); any failure makes the host loop run */
+static int cluster_scores_on_device(size_t n, const float *trans, const float *quat, const float *wv,
+                                    const int32_t *cell, const uint32_t *hash_idx, float d_dist, int use_l1,
+                                    float *score)
+{
+    int rc = OSLAM_OK;
+    char *d = NULL, *h = NULL;
+    /* pose order: trans [n][3], quat [n][4], cell [n][3]; sorted order: hash [n], quat, trans, votes; out: score */
+    const size_t o_tr = 0, o_q = o_tr + 12 * n, o_c = o_q + 16 * n, o_sh = o_c + 12 * n, o_sq = o_sh + 4 * n,
+                 o_st = o_sq + 16 * n, o_sw = o_st + 12 * n, o_sc = o_sw + 4 * n, total = o_sc + 4 * n;
+    size_t j;
+    hipStream_t st = (hipStream_t)g_stream;
+    h = (char *)malloc(total);
+    if (!h) return OSLAM_E_NOMEM;
+    memcpy(h + o_tr, trans, 12 * n);
+    memcpy(h + o_q, quat, 16 * n);
+    memcpy(h + o_c, cell, 12 * n);
+    for (j = 0; j < n; j++) {
+        const uint32_t o = hash_idx[2 * j + 1];
+        ((uint32_t *)(h + o_sh))[j] = hash_idx[2 * j];
+        memcpy(h + o_sq + 16 * j, quat + 4 * o, 16);
+        memcpy(h + o_st + 12 * j, trans + 3 * o, 12);
+        ((float *)(h + o_sw))[j] = wv[o];
+    }
+    HIPCHK(hipMalloc((void **)&d, total));
+    HIPCHK(hipMemcpyAsync(d, h, o_sc, hipMemcpyHostToDevice, st));
+    KCHK(oslamk_cluster_scores((int)n, (const float *)(d + o_tr), (const float *)(d + o_q), (const int *)(d + o_c),
+                               (const uint32_t *)(d + o_sh), (const float *)(d + o_sq), (const float *)(d + o_st),
+                               (const float *)(d + o_sw), d_dist, use_l1, (float *)(d + o_sc), g_stream));
+    HIPCHK(hipMemcpyAsync(score, d + o_sc, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+done:
+    free(h);
+    if (d) (void)hipFree(d);
+    return rc;
+}
+
 static int finish_cells(oslam_model *m, oslam_scene *s, oslam_cell *cells, size_t n, uint32_t gmax,
                         float T[16], oslam_stats *st)
 {
@@ -619,9 +656,11 @@ static int finish_cells(oslam_model *m, oslam_scene *s, oslam_cell *cells, size_
     memcpy(m->last_cells, cells, sizeof(oslam_cell) * n);
     m->n_last = n;
     if (st) { st->num_top = n; st->max_count = gmax; }
+    oslam_pose_set_cluster_hook(cluster_scores_on_device);
     rc = oslam_pose_stage(cells, n, m->c.h_xyz, m->c.h_nrm, (size_t)m->c.n, s->c.h_xyz, s->c.h_nrm,
                           (size_t)s->c.n, m->d_dist, m->params.cpu_clustering, m->params.use_l1_norm,
                           m->params.use_averaged_clusters, m->weights, T, m->last_poses);
+    oslam_pose_set_cluster_hook(NULL);
     if (rc == OSLAM_E_NO_VOTES) return fail(rc, "no scene pair matched the model");
     if (rc != OSLAM_OK) return fail(rc, "pose stage failed");
     return OSLAM_OK;
@@ -686,6 +725,7 @@ int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, 
     rc = check_pair(m, s);
     if (rc != OSLAM_OK) return rc;
     if (!stats) stats = &local;
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
     tmp = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
     if (!tmp) return fail(OSLAM_E_NOMEM, "host allocation failed");
     memcpy(tmp, cells, sizeof(oslam_cell) * n);

@@ -136,6 +136,13 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream);
  * hipError_t, or -1 when the voxel count overflows int32 */
 int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32_t *n_out, void *stream);
 
+/* clustering scores of n poses (device arrays).  shash[j] = cell hash of the j-th pose in
+ * (hash, pose index) order; sq/st/sw = quaternions [n][4], translations [n][3], weighted votes [n]
+ * in that order; trans/quat/cell in pose order.  The translation-averaging variant stays on the host. */
+int oslamk_cluster_scores(int n, const float *trans, const float *quat, const int *cell, const uint32_t *shash,
+                          const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
+                          float *score, void *stream);
+
 /* device self-test: out_acos[i] = pm_acosf(x[i]); out_atan2[i] = pm_atan2f(y[i], x2[i]);
  * out_bin[i] = pc_alpha_bin_exact(...) */
 int oslamk_selftest(const float *x, const float *y, const float *x2, size_t n, float *out_acos,

@@ -644,6 +644,74 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 }
 
 /* --------------------------------------------------------------------------
+ * pose clustering scores (rot_clustering_kernel, kernel.cu:702-763, without the in-place
+ * translation averaging): one thread per pose scans its 26 neighbour cells in the fixed
+ * (dx,dy,dz) order and sums the weighted votes of compatible poses.  Every pose's float sum
+ * has its own fixed order, so the result equals the host loop of oslam_pose.c bit for bit.
+ * sorted[] = (cell hash, pose index) ascending; a hash of 0 is never searched (kernel.cu:727).
+ * ------------------------------------------------------------------------*/
+__device__ __forceinline__ uint32_t fnv_cell3(int cx, int cy, int cz)
+{
+    uint32_t h = pm_fnv1a_word(PM_FNV_BASIS, (uint32_t)cx);
+    h = pm_fnv1a_word(h, (uint32_t)cy);
+    return pm_fnv1a_word(h, (uint32_t)cz);
+}
+
+/* One wave per pose.  The 64 lanes test 64 candidates of a neighbour cell at once (the
+ * expensive part); the compatible ones are then added by walking the ballot mask in ascending
+ * order, i.e. exactly the sequential float sum of the reference loop.  sq/st/sw are the pose
+ * quaternions, translations and weighted votes permuted into sorted (cell hash, pose index)
+ * order, so consecutive lanes read consecutive memory. */
+__global__ __launch_bounds__(64) void k_cluster_scores(int n, const float *trans, const float *quat,
+                                                       const int *cell, const uint32_t *shash,
+                                                       const float4 *sq, const float *st, const float *sw,
+                                                       float d_dist, int use_l1, float *score)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const float rot_thresh = 2 * PM_D_ANGLE, rot_thresh_sq = rot_thresh * rot_thresh;
+    const float q0 = quat[4 * i], q1 = quat[4 * i + 1], q2 = quat[4 * i + 2], q3 = quat[4 * i + 3];
+    const float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
+    const int cx = cell[3 * i], cy = cell[3 * i + 1], cz = cell[3 * i + 2];
+    float votes = 1;                                             /* kernel.cu:722 */
+    for (int dx = -1; dx < 2; dx++)
+        for (int dy = -1; dy < 2; dy++)
+            for (int dz = -1; dz < 2; dz++) {
+                if (dx == 0 && dy == 0 && dz == 0) continue;     /* kernel.cu:684-689 */
+                const uint32_t h = fnv_cell3(cx + dx, cy + dy, cz + dz);
+                if (h == 0) continue;
+                int lo = 0, hi = n;
+                while (lo < hi) {
+                    const int mid = lo + (hi - lo) / 2;
+                    if (shash[mid] < h) lo = mid + 1; else hi = mid;
+                }
+                for (int base = lo; base < n; base += WAVE) {
+                    const int j = base + lane;
+                    bool ok = false;
+                    float w = 0.0f;
+                    const bool in_cell = j < n && shash[j] == h;
+                    if (in_cell) {
+                        const float4 qo = sq[j];
+                        const float qd = fabsf(8 * (1 - (q0 * qo.x + q1 * qo.y + q2 * qo.z + q3 * qo.w)));
+                        ok = qd < rot_thresh_sq;
+                        if (ok && !use_l1) {
+                            const float ex = tx - st[3 * j], ey = ty - st[3 * j + 1], ez = tz - st[3 * j + 2];
+                            ok = pm_sqrtf(ex * ex + ey * ey + ez * ez) < d_dist;
+                        }
+                        w = sw[j];
+                    }
+                    unsigned long long m = __ballot(ok);
+                    while (m) {                                  /* ascending j: the reference's order */
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        votes += readlane_f(w, b);
+                    }
+                    if (__ballot(in_cell) != ~0ull) break;       /* the cell's run ended in this step */
+                }
+            }
+    if (lane == 0) score[i] = votes;
+}
+
+/* --------------------------------------------------------------------------
  * device self-test of the float path
  * ------------------------------------------------------------------------*/
 __global__ void k_selftest(const float *x, const float *y, const float *x2, size_t n, float *out_acos,
@@ -726,6 +794,16 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream)
         hipLaunchKernelGGL(k_vote<0>, grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
     else
         hipLaunchKernelGGL(k_vote<1>, grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+int oslamk_cluster_scores(int n, const float *trans, const float *quat, const int *cell, const uint32_t *shash,
+                          const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
+                          float *score, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_cluster_scores, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, n, trans, quat, cell,
+                       shash, reinterpret_cast<const float4 *>(sq), st, sw, d_dist, use_l1, score);
     return (int)hipGetLastError();
 }
 

@@ -127,6 +127,17 @@ size_t oslam_filter_cells(oslam_cell *cells, size_t n, float thresh, uint32_t gm
     return k;
 }
 
+/* host threads for the per-cell loops: at most 16 (a 1-GPU share of the host); below 8192 items
+ * the loops take about a millisecond and waking threads costs more than it saves */
+static int pose_threads(size_t n)
+{
+#ifdef _OPENMP
+    if (n >= 8192) return omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+#endif
+    (void)n;
+    return 1;
+}
+
 /* ---- K5: pose of one cell (kernel.cu:372-401) from the two frames ---- */
 static void cell_pose(uint64_t code, const float *Tm, const float *Ts, float *T)
 {
@@ -162,7 +173,12 @@ static int frame_cache_build(frame_cache *fc, const oslam_cell *cells, size_t n,
     fc->n = u;
     fc->T = (float *)malloc(sizeof(float) * 16 * (u ? u : 1));
     if (!fc->T) return -1;
-    for (i = 0; i < u; i++) oslam_build_T_g(xyz + 3 * (size_t)fc->idx[i], nrm + 3 * (size_t)fc->idx[i], fc->T + 16 * i);
+    {
+        long ii;
+#pragma omp parallel for schedule(static) num_threads(pose_threads(u))
+        for (ii = 0; ii < (long)u; ii++)
+            oslam_build_T_g(xyz + 3 * (size_t)fc->idx[ii], nrm + 3 * (size_t)fc->idx[ii], fc->T + 16 * ii);
+    }
     return 0;
 }
 
@@ -218,6 +234,9 @@ static size_t hash_lower_bound(const hash_idx *v, size_t n, uint32_t h)
     return lo;
 }
 
+static __thread oslam_cluster_hook g_cluster_hook;
+void oslam_pose_set_cluster_hook(oslam_cluster_hook hook) { g_cluster_hook = hook; }
+
 /* ---- K6 + K8 + K9 + argmax: returns max_idx ---- */
 static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, const float *quat,
                                float d_dist, int use_l1, int averaged, const float *weights)
@@ -242,8 +261,12 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
 
     /* Each pose scans its 26 neighbour cells in a fixed order, so its float sums do not depend
      * on the other poses -- unless translations are averaged in place (kernel.cu:747-758), which
-     * stays serial in index order.  Threads: at most 16 (a 1-GPU share of the host). */
-    {
+     * stays serial in index order.  Large sets go to the GPU (k_cluster_scores: same sums, same
+     * order), otherwise host threads: at most 16 (a 1-GPU share of the host). */
+    if (!averaged && n >= 2048 && g_cluster_hook &&
+        g_cluster_hook(n, trans, quat, wv, cell, (const uint32_t *)hi, d_dist, use_l1, score) == 0) {
+        /* scores are in place */
+    } else {
         long ii;
         int threads = 1;
 #ifdef _OPENMP
@@ -428,10 +451,14 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
             free(fs.idx); free(fs.T); free(fm.idx); free(fm.T); free(poses);
             return OSLAM_E_NOMEM;
         }
-        for (i = 0; i < n; i++) {
-            if ((cells[i].code >> 32) == 0 && ((uint32_t)cells[i].code) == 0) continue;   /* :628-631 */
-            cell_pose(cells[i].code, frame_cache_get(&fm, ((uint32_t)cells[i].code) >> 6),
-                      frame_cache_get(&fs, (uint32_t)(cells[i].code >> 32)), poses + 16 * i);
+        {
+            long ii;
+#pragma omp parallel for schedule(static) num_threads(pose_threads(n))
+            for (ii = 0; ii < (long)n; ii++) {
+                if ((cells[ii].code >> 32) == 0 && ((uint32_t)cells[ii].code) == 0) continue;   /* :628-631 */
+                cell_pose(cells[ii].code, frame_cache_get(&fm, ((uint32_t)cells[ii].code) >> 6),
+                          frame_cache_get(&fs, (uint32_t)(cells[ii].code >> 32)), poses + 16 * ii);
+            }
         }
         free(fs.idx); free(fs.T); free(fm.idx); free(fm.T);
     }

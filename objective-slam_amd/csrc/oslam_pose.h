@@ -20,6 +20,14 @@ extern "C" {
 void oslam_T_g_rows(const float *xyz, const float *nrm, const uint32_t *idx, size_t n,
                     float *rows_out);
 
+/* Optional accelerator for the clustering scores (set by oslam_host.c while a device is bound):
+ * fills score[n] exactly as the host loop would, returns 0 on success.  hash_idx = n pairs
+ * {cell hash, pose index} ascending. */
+typedef int (*oslam_cluster_hook)(size_t n, const float *trans, const float *quat, const float *wv,
+                                  const int32_t *cell, const uint32_t *hash_idx, float d_dist, int use_l1,
+                                  float *score);
+void oslam_pose_set_cluster_hook(oslam_cluster_hook hook);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,7 +239,7 @@ def test_full_size_sample_against_oracle(ppf, oracle, built_lib, full_size):
     fm.close()
 
 
-def test_full_size_properties(ppf, built_lib, full_size):
+def test_full_size_properties(ppf, oracle, built_lib, full_size):
     c = full_size
     par = ppf.default_params()
     sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=8, params=par)
@@ -249,6 +249,14 @@ def test_full_size_properties(ppf, built_lib, full_size):
     T2 = mo.ppf_lookup(sc)                                           # determinism / idempotence
     assert np.array_equal(T1, T2) and cells_equal(cells1, mo.last_cells()[0])
     assert st1["num_scene_ppfs"] == 12500 * 99999
+    # 4350 cells: the clustering scores come from the GPU kernel (>= 2048 cells); the oracle's
+    # serial host-order loop must give the same pose, for both clustering norms
+    assert len(cells1) >= 2048
+    rc, To = oracle.pose_from_cells(cells1, c["mp"], c["mn"], c["sp"], c["sn"], c["d"])
+    assert np.array_equal(T1, To)
+    ml1 = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], use_l1_norm=True)
+    rc, To = oracle.pose_from_cells(cells1, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], use_l1_norm=True)
+    assert np.array_equal(ml1.ppf_lookup(sc), To)
     # shards partition the votes and their union reproduces the single-GPU cells and pose
     tot_votes = tot_hits = 0
     parts, gmax = [], 0
