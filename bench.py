@@ -74,6 +74,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # torch.distributed.run exports OMP_NUM_THREADS=1; the host stage (poses of the gathered peaks)
+    # uses up to 16 threads per rank -- 128 on an 8-GPU node -- and reads this when the library loads
+    if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
+        os.environ["OMP_NUM_THREADS"] = "16"
     pkg = importlib.import_module("objective-slam_amd")
     ppf, synth = pkg.ppf, pkg.synth
 
