@@ -74,12 +74,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    # torch.distributed.run exports OMP_NUM_THREADS=1; the host stage (poses of the gathered peaks)
-    # uses up to 16 threads per rank -- 128 on an 8-GPU node -- and reads this when the library loads
-    if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
-        os.environ["OMP_NUM_THREADS"] = "16"
     pkg = importlib.import_module("objective-slam_amd")
     ppf, synth = pkg.ppf, pkg.synth
+    # torch.distributed.run exports OMP_NUM_THREADS=1 per rank; the host stage (poses of the gathered
+    # peaks) may use a few threads: 8 per rank is 64 on an 8-GPU node
+    if world > 1:
+        ppf.set_host_threads(min(8, max(1, len(os.sched_getaffinity(0)) // world)))
 
     M, S = args.model_points, args.scene_points
     df = args.df if args.df > 0 else max(1, 8 // world)

@@ -192,6 +192,9 @@ int oslam_last_cells(oslam_model *m, oslam_cell *cells_out, float *poses_out, si
  * NULL = the default stream).  bench.py passes torch's current stream. */
 int oslam_set_stream(void *hip_stream);
 const char *oslam_last_error(void);
+/* Threads of the host stage (poses and clustering of the gathered peaks); 0 = OpenMP's default,
+ * capped at 16.  Launchers that export OMP_NUM_THREADS=1 per rank can raise it here. */
+int oslam_set_host_threads(int n);
 /* Self-test of the device float path against the host: evaluates pm_acosf /
  * pm_atan2f / key arithmetic on `n` pseudo-random inputs on both sides and
  * returns the number of mismatching results in *mismatches. */

@@ -127,12 +127,23 @@ size_t oslam_filter_cells(oslam_cell *cells, size_t n, float thresh, uint32_t gm
     return k;
 }
 
-/* host threads for the per-cell loops: at most 16 (a 1-GPU share of the host); below 8192 items
- * the loops take about a millisecond and waking threads costs more than it saves */
+static int g_host_threads;      /* 0: OpenMP's default (OMP_NUM_THREADS), capped at 16 */
+
+int oslam_set_host_threads(int n)
+{
+    g_host_threads = n > 0 ? n : 0;
+    return OSLAM_OK;
+}
+
+/* host threads for the per-cell loops: at most 16 by default (a 1-GPU share of the host); below
+ * 8192 items the loops take about a millisecond and waking threads costs more than it saves */
 static int pose_threads(size_t n)
 {
 #ifdef _OPENMP
-    if (n >= 8192) return omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+    if (n >= 8192) {
+        if (g_host_threads) return g_host_threads;
+        return omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+    }
 #endif
     (void)n;
     return 1;
@@ -270,7 +281,7 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
         long ii;
         int threads = 1;
 #ifdef _OPENMP
-        threads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+        threads = g_host_threads ? g_host_threads : (omp_get_max_threads() < 16 ? omp_get_max_threads() : 16);
         if (averaged || n < 512) threads = 1;
 #endif
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads)

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "oslam_last_cells": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_set_stream": (_i, [_vp]),
     "oslam_last_error": (C.c_char_p, []),
+    "oslam_set_host_threads": (_i, [_i]),
     "oslam_selftest_math": (_i, [_sz, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
@@ -374,6 +375,10 @@ def selftest_math(n=1 << 20, seed=1):
     bad = C.c_uint64(0)
     _check(lib().oslam_selftest_math(int(n), int(seed), C.byref(bad)))
     return int(bad.value)
+
+
+def set_host_threads(n):
+    _check(lib().oslam_set_host_threads(int(n)))
 
 
 def set_stream(stream_ptr):
