@@ -466,7 +466,7 @@ static scratch_pool g_pool[MAX_DEVICES];
 static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratch_pool **pool_out, int *batch_out)
 {
     int rc = OSLAM_OK;
-    const size_t per_ref = (size_t)s->c.n * sizeof(oslamk_hit);
+    const size_t per_ref = 2 * (size_t)s->c.n * sizeof(oslamk_hit);     /* arrival order + sorted by key */
     size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)8 << 30;
     const char *env = getenv("OSLAM_SCRATCH_GIB");
     scratch_pool *p;
@@ -526,6 +526,7 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.dump_ref = -1;
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
     a.hits = pool->hits;
+    a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
     a.hit_count = pool->hit_count;
     a.hit_stride = (size_t)s->c.n;
     HIPCHK(hipEventCreate(&e0));
@@ -542,6 +543,7 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
             HIPCHK(hipEventRecord(ev[3 * nb], st));
         }
         KCHK(oslamk_scene_hits(&a, g_stream));
+        KCHK(oslamk_sort_hits(&a, g_stream));
         if (timed) HIPCHK(hipEventRecord(ev[3 * nb + 1], st));
         KCHK(oslamk_vote(&a, g_stream));
         if (timed) HIPCHK(hipEventRecord(ev[3 * nb + 2], st));
@@ -904,11 +906,13 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
         rc = ensure_hit_scratch(m, s, &pool, &batch);
         if (rc != OSLAM_OK) goto done;
         a.hits = pool->hits;
+        a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
         a.hit_count = pool->hit_count;
     }
     a.hit_stride = (size_t)s->c.n;
     HIPCHK(hipMemsetAsync(a.hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));
     KCHK(oslamk_scene_hits(&a, g_stream));
+    KCHK(oslamk_sort_hits(&a, g_stream));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), (hipStream_t)g_stream));
     KCHK(oslamk_vote(&a, g_stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));

@@ -122,6 +122,7 @@ typedef struct oslamk_vote_args {
     /* per-reference hit lists of this batch (written by oslamk_scene_hits, read by oslamk_vote):
      * hits[ref_local * hit_stride + k] = {key, vy bits, vz bits, theta_v}, k < hit_count[ref_local] */
     oslamk_hit *hits;
+    oslamk_hit *hits_sorted;   /* the same lists sorted by key (oslamk_sort_hits) -- what oslamk_vote reads */
     uint32_t *hit_count;
     size_t hit_stride;
 } oslamk_vote_args;
@@ -129,7 +130,9 @@ typedef struct oslamk_vote_args {
 /* scene pair keys -> per-reference hit lists, for reference ordinals first_ref..+n_launch-1;
  * hit_count[0..n_launch) must be zero on entry */
 int oslamk_scene_hits(const oslamk_vote_args *a, void *stream);
-/* votes of the same batch (needs the hit lists) */
+/* hit lists -> hits_sorted (by key), same batch */
+int oslamk_sort_hits(const oslamk_vote_args *a, void *stream);
+/* votes of the same batch (needs the sorted hit lists) */
 int oslamk_vote(const oslamk_vote_args *a, void *stream);
 
 /* voxel grid (oslam_voxel.hip): out6 = device [n][6] (x y z nx ny nz per voxel); returns a

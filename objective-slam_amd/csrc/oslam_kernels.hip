@@ -28,9 +28,6 @@
 #ifndef VOTE_PIPE
 #define VOTE_PIPE 1       /* chunks in flight ahead of the one being voted (1 measured best) */
 #endif
-#ifndef VOTE_U
-#define VOTE_U 1          /* 16-byte loads per lane per chunk: 256*VOTE_U entries per wave */
-#endif
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
 
@@ -244,15 +241,17 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
-/* which chunk of which bucket (wave-uniform) */
+/* which chunk of which bucket, and which hits share it (all wave-uniform): the hits of a
+ * reference point are sorted by key (k_sort_hits), so hits with the same key sit in consecutive
+ * lanes and the bucket is streamed once for the whole run */
 struct ChunkDesc {
-    uint32_t st, off, ln, cs2;
-    float vy, vz;
-    bool valid, forced;
+    uint32_t st, off, ln;      /* bucket start, offset of this chunk, bucket length */
+    int head, run;             /* first lane of the run and number of hits in it */
+    bool valid, bforced;       /* bforced: the bucket holds an entry with the marker */
 };
 
-/* A chunk of VOTE_U x 256 model-pair entries held in registers by one wave: lane l holds
- * entries 4*(u*64 + l) .. +3 of the chunk (one 16-byte load each; VOTE_U = 1 measured best).
+/* A chunk of 256 model-pair entries held in registers by one wave: lane l holds entries
+ * 4l .. 4l+3 of the chunk (one 16-byte load).
  * A vote: theta_v - theta_u in units of 2^-17 bin gives bin and position in the bin; only
  * positions within 2^-12 bin of an edge (0.05 % of votes) are re-evaluated with the reference's
  * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's.
@@ -292,47 +291,55 @@ struct SlowQueue {
 
 template <int MODE>
 struct Chunk {
-    static constexpr int U = VOTE_U;
-    uint4 v[U];
-    __device__ __forceinline__ void load(const oslamk_vote_args &a, uint32_t st, uint32_t off,
-                                         uint32_t ln, int lane)
+    uint4 v;
+    __device__ __forceinline__ void load(const oslamk_vote_args &a, const ChunkDesc &d, int lane)
     {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t e = off + 4u * (u * WAVE + lane);
-            if (e < ln) v[u] = *reinterpret_cast<const uint4 *>(&a.ent.e4[(size_t)st + e]);
-        }
+        const uint32_t e = d.off + 4u * (uint32_t)lane;
+        if (e < d.ln) v = *reinterpret_cast<const uint4 *>(&a.ent.e4[(size_t)d.st + e]);
     }
-    /* cs2 = (theta_v + 15 bins) mod one turn.  Votes that need the reference's float sequence
-     * are not evaluated here (their operands are a dependent gather that would stall the
-     * stream): they are queued per wave and evaluated 64 at a time by SlowQueue::flush. */
+    /* All hits of the run vote with this chunk.  cs2v / fv / vyv / vzv: per-lane data of the
+     * wave's 64 hits (cs2 = (theta_v + 15 bins) mod one turn; fv = theta_v is the marker).
+     * Votes that need the reference's float sequence are queued (their operands are a dependent
+     * gather that would stall the stream) and evaluated 64 at a time by SlowQueue::flush. */
     __device__ __forceinline__ void vote(const oslamk_vote_args &a, uint32_t *acc, const uint32_t *tbl,
-                                         SlowQueue &sq, uint32_t st, uint32_t off, uint32_t ln, int lane,
-                                         uint32_t cs2, bool forced, float vy, float vz) const
+                                         SlowQueue &sq, const ChunkDesc &d, int lane, uint32_t cs2v, bool fv,
+                                         float vyv, float vzv) const
     {
+        const uint32_t e = d.off + 4u * (uint32_t)lane;
+        const int rem = (int)d.ln - (int)e;                  /* entries of this lane that exist */
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t am[4], row[4];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t e = off + 4u * (u * WAVE + lane);
-            const int rem = (int)ln - (int)e;                /* entries of this lane that exist */
-            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        for (int j = 0; j < 4; j++) {
+            am[j] = w[j] & 0x3fffffu;
+            /* accumulator row of the entry, or the lane's trash word (then the bin must add 0) */
+            row[j] = rem > j ? (w[j] >> 22) << 5 : ACC_TRASH + (uint32_t)lane;
+        }
+        for (int i = 0; i < d.run; i++) {
+            const int li = d.head + i;
+            const uint32_t cs2 = readlane_u(cs2v, li);
+            const bool forced = d.bforced || (readlane_u((uint32_t)fv, li) != 0);
             uint32_t idx[4];
             bool need[4];
+            bool any_need = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t t = cs2 - (w[j] & 0x3fffffu);       /* in (-turn, turn) */
+                uint32_t t = cs2 - am[j];                    /* in (-turn, turn) */
                 const uint32_t t_wrapped = t + PC_Q17_TURN;
                 t = t < t_wrapped ? t : t_wrapped;           /* unsigned min = mod one turn */
-                idx[j] = rem > j ? ((w[j] >> 22) << 5) + (t >> 17) : ACC_TRASH + (uint32_t)lane;
+                idx[j] = row[j] + (rem > j ? t >> 17 : 0u);
                 /* within PC_Q17_MARGIN of a bin edge (either side)?  forced: every vote of the bucket */
                 need[j] = MODE == 0 && rem > j &&
                           (forced || ((t - PC_Q17_MARGIN) & (PC_Q17_ONE - 1u)) >= PC_Q17_ONE - 2u * PC_Q17_MARGIN);
+                any_need = any_need || need[j];
             }
-            if (MODE == 0 && __any(need[0] || need[1] || need[2] || need[3])) {
+            if (MODE == 0 && __any(any_need)) {
+                const float vy = readlane_f(vyv, li), vz = readlane_f(vzv, li);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const unsigned long long nm = __ballot(need[j]);
                     if (nm) {
-                        sq.push(nm, need[j], lane, st + e + j, w[j] >> 22, vy, vz);
+                        sq.push(nm, need[j], lane, d.st + e + j, w[j] >> 22, vy, vz);
                         if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, acc, tbl, lane);
                         if (need[j]) idx[j] = ACC_TRASH + (uint32_t)lane;
                     }
@@ -426,6 +433,44 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
     }
 }
 
+/* Sorts the hit list of each reference point of the batch by key, so that hits that share a
+ * bucket are adjacent (on the bench scene a bucket is hit 3.8 times per reference point on
+ * average; streaming it once per run cuts the entry traffic 4.7x).  One workgroup per reference
+ * point: bitonic sort of (key << 32 | index) in LDS, then the records are gathered into the
+ * second list.  Lists longer than SORT_MAX stay in arrival order (still correct, runs are just
+ * short). */
+#define SORT_MAX 16384
+__global__ __launch_bounds__(1024) void k_sort_hits(oslamk_vote_args a)
+{
+    __shared__ unsigned long long buf[SORT_MAX];
+    const int ref_local = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = a.hit_count[ref_local];
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
+    uint4 *dst = reinterpret_cast<uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
+    if (n > SORT_MAX) {
+        for (uint32_t i = tid; i < n; i += 1024) dst[i] = src[i];
+        return;
+    }
+    uint32_t P = 64;
+    while (P < n) P <<= 1;
+    for (uint32_t i = tid; i < P; i += 1024)
+        buf[i] = i < n ? ((unsigned long long)src[i].x << 32) | i : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < P / 2; t += 1024) {
+                /* t-th compare-exchange of this pass: partner indices differ in bit j */
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const unsigned long long x = buf[lo], y = buf[hi];
+                const bool up = (lo & k) == 0;
+                if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < n; i += 1024) dst[i] = src[(uint32_t)buf[i]];
+}
+
 /* One workgroup = one (scene reference point, model slice).
  * LDS: acc[1024][32] u32 = 128 KiB (one workgroup per CU, 16 waves).
  * ComputeUniqueVotes (model.cu:95-171) without the vote list: K3/K4
@@ -450,7 +495,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const int slice = (int)(blockIdx.x % n_slices);
     const uint32_t r = a.ref_idx[ref_ord];
     const uint32_t n_hits = a.hit_count[ref_local];
-    const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
+    const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
 
     for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) acc[c] = 0;
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
@@ -466,66 +511,68 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 
     for (uint32_t base = 0; base < n_hits; base += VOTE_THREADS) {
         const uint32_t h = base + tid;
-        uint32_t start = 0, len = 0, cs = 0;
-        float vy = 0.0f, vz = 0.0f;
-        if (h < n_hits) {
+        const bool have = h < n_hits;
+        uint32_t key = 0, cs2v = 0;
+        bool fv = false;
+        float vyv = 0.0f, vzv = 0.0f;
+        if (have) {
             const uint4 rec = hits[h];
-            uint32_t slot = slot_of(rec.x, shift);
+            uint32_t c = rec.w + 15u * PC_Q17_ONE;
+            key = rec.x;
+            vyv = __builtin_bit_cast(float, rec.y);
+            vzv = __builtin_bit_cast(float, rec.z);
+            fv = rec.w == PC_Q17_FORCE;
+            cs2v = c >= PC_Q17_TURN ? c - PC_Q17_TURN : c;
+            if (slice == 0) my_hits += 1;
+        }
+        /* runs of equal keys inside this wave's 64 hits: the first lane of a run probes the
+         * slice table; the run ends where the next one starts (or at the last hit) */
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, WAVE);
+        const bool is_head = have && (lane == 0 || key != prev);
+        const unsigned long long heads = __ballot(is_head), haves = __ballot(have);
+        uint32_t start = 0, len = 0, bflag = 0;
+        int run = 0;
+        if (is_head) {
+            const unsigned long long later = heads & ~((2ull << lane) - 1ull);   /* heads above this lane */
+            const int end = later ? __ffsll((long long)later) - 1 : __popcll(haves);
+            run = end - lane;
+            uint32_t slot = slot_of(key, shift);
             for (uint32_t probe = 0; probe <= mask; probe++) {
                 const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
-                if (sv.x == rec.x) {
+                if (sv.x == key) {
                     start = sv.y;
                     len = sv.z;
-                    my_votes += len;
-                    if (sv.w >> 31) cs = PC_Q17_FORCE;       /* the bucket holds an entry with the marker */
+                    bflag = sv.w >> 31;                       /* the bucket holds an entry with the marker */
+                    my_votes += (unsigned long long)len * (unsigned)run;
                     break;
                 }
                 if (sv.x == 0) break;
                 slot = (slot + 1) & mask;
             }
-            vy = __builtin_bit_cast(float, rec.y);
-            vz = __builtin_bit_cast(float, rec.z);
-            if (cs != PC_Q17_FORCE) cs = rec.w;
-            if (slice == 0) my_hits += 1;
         }
-        /* wave-cooperative sweep: all 64 lanes stream one bucket at a time, in chunks of
-         * CH::U x 256 entries; the next chunk's loads (possibly of the next bucket) are in
-         * flight while the current chunk votes */
-        /* chunk generator over this wave's hit buckets (all state wave-uniform) */
+        /* wave-cooperative sweep: all 64 lanes stream one bucket at a time in chunks of 256
+         * entries, every hit of the run votes with the chunk, and the next chunk's load
+         * (possibly of the next bucket) is in flight meanwhile.  Generator state is wave-uniform. */
         unsigned long long todo = __ballot(len > 0);
-        auto set_cs = [](ChunkDesc &d, uint32_t csq) {
-            uint32_t c = csq + 15u * PC_Q17_ONE;
-            d.forced = csq == PC_Q17_FORCE;
-            d.cs2 = c >= PC_Q17_TURN ? c - PC_Q17_TURN : c;
-        };
         ChunkDesc g;                       /* the next chunk to hand out */
         g.valid = todo != 0;
-        if (g.valid) {
-            const int l = __ffsll((long long)todo) - 1;
+        auto open_bucket = [&](int l) {
             g.st = readlane_u(start, l);
             g.ln = readlane_u(len, l);
-            set_cs(g, readlane_u(cs, l));
-            g.vy = readlane_f(vy, l);
-            g.vz = readlane_f(vz, l);
+            g.head = l;
+            g.run = (int)readlane_u((uint32_t)run, l);
+            g.bforced = readlane_u(bflag, l) != 0;
             g.off = 0;
-        }
+        };
+        if (g.valid) open_bucket(__ffsll((long long)todo) - 1);
         auto next_chunk = [&]() -> ChunkDesc {
             const ChunkDesc out = g;
             if (g.valid) {
-                g.off += CH::U * WAVE * 4;
+                g.off += 4 * WAVE;
                 if (g.off >= g.ln) {
                     todo &= todo - 1;
-                    if (todo) {
-                        const int l = __ffsll((long long)todo) - 1;
-                        g.st = readlane_u(start, l);
-                        g.ln = readlane_u(len, l);
-                        set_cs(g, readlane_u(cs, l));
-                        g.vy = readlane_f(vy, l);
-                        g.vz = readlane_f(vz, l);
-                        g.off = 0;
-                    } else {
-                        g.valid = false;
-                    }
+                    if (todo) open_bucket(__ffsll((long long)todo) - 1);
+                    else g.valid = false;
                 }
             }
             return out;
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 #pragma unroll
         for (int i = 0; i < VOTE_PIPE; i++) {
             d[i] = next_chunk();
-            if (d[i].valid) c[i].load(a, d[i].st, d[i].off, d[i].ln, lane);
+            if (d[i].valid) c[i].load(a, d[i], lane);
         }
         while (d[0].valid) {
             const CH cur = c[0];
@@ -547,9 +594,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                 d[i] = d[i + 1];
             }
             d[VOTE_PIPE - 1] = next_chunk();
-            if (d[VOTE_PIPE - 1].valid)
-                c[VOTE_PIPE - 1].load(a, d[VOTE_PIPE - 1].st, d[VOTE_PIPE - 1].off, d[VOTE_PIPE - 1].ln, lane);
-            cur.vote(a, acc, s_tbl, sq, dc.st, dc.off, dc.ln, lane, dc.cs2, dc.forced, dc.vy, dc.vz);
+            if (d[VOTE_PIPE - 1].valid) c[VOTE_PIPE - 1].load(a, d[VOTE_PIPE - 1], lane);
+            cur.vote(a, acc, s_tbl, sq, dc, lane, cs2v, fv, vyv, vzv);
         }
     }
     if (MODE == 0) sq.flush(a, acc, s_tbl, lane);
@@ -783,6 +829,13 @@ int oslamk_scene_hits(const oslamk_vote_args *a, void *stream)
     if (a->n_launch <= 0) return 0;
     dim3 grid((unsigned)((a->scene.n + KEY_TILE - 1) / KEY_TILE), (unsigned)a->n_launch);
     hipLaunchKernelGGL(k_scene_hits, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
+int oslamk_sort_hits(const oslamk_vote_args *a, void *stream)
+{
+    if (a->n_launch <= 0) return 0;
+    hipLaunchKernelGGL(k_sort_hits, dim3((unsigned)a->n_launch), dim3(1024), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }
 
