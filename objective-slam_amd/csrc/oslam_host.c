@@ -466,7 +466,8 @@ static scratch_pool g_pool[MAX_DEVICES];
 static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratch_pool **pool_out, int *batch_out)
 {
     int rc = OSLAM_OK;
-    const size_t per_ref = 2 * (size_t)s->c.n * sizeof(oslamk_hit);     /* arrival order + sorted by key */
+    /* per reference point: hits in arrival order + sorted by key (16 B each) + run list (8 B each, + end marker) */
+    const size_t per_ref = 2 * (size_t)s->c.n * sizeof(oslamk_hit) + ((size_t)s->c.n + 1) * 2 * sizeof(uint32_t);
     size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)8 << 30;
     const char *env = getenv("OSLAM_SCRATCH_GIB");
     scratch_pool *p;
@@ -486,7 +487,7 @@ static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratc
     if (batch > 65535) batch = 65535;            /* grid.y of the scene-key kernel */
     if (p->hit_count_cap < batch) {
         if (p->hit_count) { (void)hipFree(p->hit_count); p->hit_count = NULL; p->hit_count_cap = 0; }
-        HIPCHK(hipMalloc((void **)&p->hit_count, sizeof(uint32_t) * batch));
+        HIPCHK(hipMalloc((void **)&p->hit_count, sizeof(uint32_t) * 2 * batch));   /* hit counts, run counts */
         p->hit_count_cap = batch;
     }
     *pool_out = p;
@@ -529,6 +530,8 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
     a.hit_count = pool->hit_count;
     a.hit_stride = (size_t)s->c.n;
+    a.runs = (uint32_t *)(pool->hits + 2 * (size_t)batch * (size_t)s->c.n);
+    a.run_count = pool->hit_count + pool->hit_count_cap;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
@@ -584,6 +587,16 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
         cnt->gmax = g;
         if (cnt->out_count > m->out_cap)
             return fail(OSLAM_E_LIMIT, "more accumulator peaks than params.max_cells");
+    }
+    if (getenv("OSLAM_PROF"))
+        fprintf(stderr, "[oslam prof] wave cycles: to end of voting %llu, building items %llu, epilogue %llu, in vote steps %llu\n",
+                cnt->prof[0], cnt->prof[1], cnt->prof[2], cnt->prof[3]);
+    if (getenv("OSLAM_PROF")) {
+        int c;
+        for (c = 0; c < 5; c++)
+            fprintf(stderr, "[oslam prof] bucket class %d: units %llu votes %llu (lanes used %.3f)\n", c, cnt->prof[4 + c],
+                    cnt->prof[9 + c], cnt->prof[4 + c] ? (double)cnt->prof[9 + c] / (256.0 * (double)cnt->prof[4 + c]) : 0.0);
+        fprintf(stderr, "[oslam prof] items %llu chunk loads %llu\n", cnt->prof[14], cnt->prof[15]);
     }
     *n_cells = cnt->out_count;
     if (*n_cells) {
@@ -908,6 +921,8 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
         a.hits = pool->hits;
         a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
         a.hit_count = pool->hit_count;
+        a.runs = (uint32_t *)(pool->hits + 2 * (size_t)batch * (size_t)s->c.n);
+        a.run_count = pool->hit_count + pool->hit_count_cap;
     }
     a.hit_stride = (size_t)s->c.n;
     HIPCHK(hipMemsetAsync(a.hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));

@@ -28,7 +28,7 @@ typedef struct oslamk_slot {
 /* Model pair entries, bucketed by (slice, key); every bucket starts on a multiple of 4
  * entries so that a lane can fetch 4 of them with one 16-byte load.
  *   e4[e] = (m_r - slice*OSLAMK_SLICE) << 22 | theta_u   the 4 bytes a vote streams
- *           (theta_u = pc_angle_q17 of (T_m_g * m_i).y/.z, kernel.cu:330-332)
+ *           (theta_u = pc_angle_t22 of (T_m_g * m_i).y/.z, kernel.cu:330-332)
  *   uv[e] = (T_m_g * m_i).y/.z as floats: read only by the rare votes that are
  *           re-evaluated with the reference's own arithmetic (exact mode)
  *   mi[e] = m_i (parity tap only) */
@@ -71,6 +71,7 @@ typedef struct oslamk_counters {
     uint32_t gmax;
     uint32_t out_count;
     uint32_t pad[2];
+    unsigned long long prof[16]; /* -DVOTE_PROF builds: wave cycles to the end of voting / to the barrier / epilogue / in vote steps */
 } oslamk_counters;
 
 typedef struct oslamk_cell {
@@ -98,7 +99,7 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
                       const float *tmg, oslamk_entries ent, void *stream);
 
 typedef struct oslamk_hit {
-    uint32_t key, vy_bits, vz_bits, theta_q17;
+    uint32_t key, vy_bits, vz_bits, theta_t22;
 } oslamk_hit;
 
 typedef struct oslamk_vote_args {
@@ -125,6 +126,10 @@ typedef struct oslamk_vote_args {
     oslamk_hit *hits_sorted;   /* the same lists sorted by key (oslamk_sort_hits) -- what oslamk_vote reads */
     uint32_t *hit_count;
     size_t hit_stride;
+    /* run lists (written by oslamk_sort_hits): runs[ref_local * (hit_stride + 1) + u] = {key, first hit
+     * of the run in hits_sorted}, u <= run_count[ref_local]; the last one is the end marker {0, hit_count} */
+    uint32_t *runs;
+    uint32_t *run_count;
 } oslamk_vote_args;
 
 /* scene pair keys -> per-reference hit lists, for reference ordinals first_ref..+n_launch-1;

@@ -196,10 +196,10 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
     const float *rows = tmg + 8 * (size_t)m_r;
     float uy = pc_row_dot(rows, x, y, z), uz = pc_row_dot(rows + 4, x, y, z);
     {
-        const uint32_t th = pc_angle_q17(uy, uz);
+        const uint32_t th = pc_angle_t22(uy, uz);
         /* a marker forces the whole bucket through the exact path: flagged in bit 31 of the cursor */
-        if (th == PC_Q17_FORCE) atomicOr(&tab[slot].cur, 0x80000000u);
-        ent.e4[e] = ((uint32_t)(m_r - slice * OSLAMK_SLICE) << 22) | (th == PC_Q17_FORCE ? 0u : th);
+        if (th == PC_T22_FORCE) atomicOr(&tab[slot].cur, 0x80000000u);
+        ent.e4[e] = ((uint32_t)(m_r - slice * OSLAMK_SLICE) << 22) | (th == PC_T22_FORCE ? 0u : th);
     }
     ent.mi[e] = (uint16_t)i;
     if (ent.uv) {
@@ -240,114 +240,180 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
+/* v_mul_hi_u32_u24 / v_mul_u32_u24 by PC_T24_SCALE, written out so that the compiler keeps the
+ * two halves apart (from the C expression it builds a 64-bit shift of both) */
+__device__ __forceinline__ uint32_t mul24_hi_7680(uint32_t a)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, 0x1e00, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t mul24_lo_7680(uint32_t a)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, 0x1e00, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+/* a value every lane holds, moved to scalar registers */
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
+{
+    return ((unsigned long long)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v);
+}
 
-/* which chunk of which bucket, and which hits share it (all wave-uniform): the hits of a
- * reference point are sorted by key (k_sort_hits), so hits with the same key sit in consecutive
- * lanes and the bucket is streamed once for the whole run */
-struct ChunkDesc {
-    uint32_t st, off, ln;      /* bucket start, offset of this chunk, bucket length */
-    int head, run;             /* first lane of the run and number of hits in it */
-    bool valid, bforced;       /* bforced: the bucket holds an entry with the marker */
-};
+/* ---- the vote of one (model pair entry, scene hit) ---------------------------
+ * A wave holds a chunk of 256 model-pair entries in registers: lane l has entries 4l .. 4l+3
+ * of the chunk (one 16-byte load).  Every hit of the run votes with the chunk:
+ *     tm  = hit's base (4*(theta_v + half a turn) + margin, one SGPR) - 4*theta_u
+ *     bin = v_mul_hi_u32_u24(tm, 7680);  position = v_mul_u32_u24(tm, 7680)
+ * Only positions within the margin of a bin edge (0.05 % of votes) are re-evaluated with the
+ * reference's float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the
+ * reference's.  The code is straight-line: lanes past the end of the bucket add into trash
+ * words behind the accumulator instead of branching around the atomic. */
+#define ACC_TRASH ACC_CELLS            /* 64 + 32 words: lane's word + bin */
+#define ACC_TRASH_WORDS 96
 
-/* A chunk of 256 model-pair entries held in registers by one wave: lane l holds entries
- * 4l .. 4l+3 of the chunk (one 16-byte load).
- * A vote: theta_v - theta_u in units of 2^-17 bin gives bin and position in the bin; only
- * positions within 2^-12 bin of an edge (0.05 % of votes) are re-evaluated with the reference's
- * float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the reference's.
- * The code is straight-line: lanes past the end of the bucket add into a per-lane trash word
- * behind the accumulator instead of branching around the atomic. */
-#define ACC_TRASH ACC_CELLS            /* 64 words, one per lane */
-
-/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table:
- * {entry index, local model reference, v.y, v.z}. */
+/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index, hit index};
+ * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
+ * a time by flush(). */
 struct SlowQueue {
     static constexpr uint32_t CAP = 96;
-    uint4 *q;
+    unsigned long long *q;              /* entry index | hit index << 32 */
     uint32_t n;                        /* wave-uniform */
-    __device__ __forceinline__ void push(unsigned long long mask, bool mine, int lane, uint32_t entry,
-                                         uint32_t mr, float vy, float vz)
+    __device__ __forceinline__ void push(unsigned long long mask, int lane, uint32_t entry, uint32_t hit)
     {
-        if (mine) {
+        if ((mask >> lane) & 1ull) {
             const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            q[n + rank] = make_uint4(entry, mr, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz));
+            q[n + rank] = (unsigned long long)entry | ((unsigned long long)hit << 32);
         }
         n += (uint32_t)__popcll(mask);
     }
-    __device__ __forceinline__ void flush(const oslamk_vote_args &a, uint32_t *acc, const uint32_t *tbl, int lane)
-    {
-        for (uint32_t base = 0; base < n; base += WAVE) {
-            if (base + lane < n) {
-                const uint4 it = q[base + lane];
-                const float2 uv = *reinterpret_cast<const float2 *>(&a.ent.uv[it.x]);
-                const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, __builtin_bit_cast(float, it.z),
-                                                        __builtin_bit_cast(float, it.w), tbl);
-                if (bin < OSLAMK_NBIN) atomicAdd(&acc[(it.y << 5) + bin], 1u);
-            }
+    __device__ __forceinline__ void flush(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
+                                          const uint32_t *tbl, int lane);
+};
+
+/* LDS pointers of the out-of-line flush */
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+
+/* Out of line on purpose: inlined, its loads make the compiler wait for the prefetched chunk at the
+ * top of the vote loop (it cannot tell the two apart at the loop head); a call site settles that. */
+__device__ __noinline__ void slow_queue_flush(const uint32_t *e4, const oslamk_uv *uvs, const uint4 *hits,
+                                              lds_u32 *acc, lds_u32 *tbl, lds_cu64 *q, uint32_t n, int lane)
+{
+    const uint32_t *t = (const uint32_t *)tbl;
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        if (base + lane < n) {
+            const unsigned long long it = q[base + lane];
+            const uint32_t entry = (uint32_t)it;
+            const uint32_t mr = e4[entry] >> 22;
+            const float2 uv = *reinterpret_cast<const float2 *>(&uvs[entry]);
+            const uint4 h = hits[(uint32_t)(it >> 32)];
+            const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, __builtin_bit_cast(float, h.y),
+                                                    __builtin_bit_cast(float, h.z), t);
+            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[(mr << 5) + bin], 1u);
         }
-        n = 0;
     }
+}
+
+__device__ __forceinline__ void SlowQueue::flush(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
+                                                 const uint32_t *tbl, int lane)
+{
+    if (n)
+        slow_queue_flush(a.ent.e4, a.ent.uv, hits, (lds_u32 *)acc, (lds_u32 *)tbl, (lds_cu64 *)q, n, lane);
+    n = 0;
+}
+
+/* One step of a wave (all fields wave-uniform): chunk `off` of the bucket [st, st+ln) voted by the
+ * hits h0+i0 .. h0+i1-1 of the run (a run piece has at most 64 hits, one per lane). */
+struct VoteStep {
+    uint32_t st, off, ln, h0, R;
+    int i0, i1;
+    bool bforced, valid;               /* bforced: the bucket holds an entry with the marker */
 };
 
 template <int MODE>
-struct Chunk {
-    uint4 v;
-    __device__ __forceinline__ void load(const oslamk_vote_args &a, const ChunkDesc &d, int lane)
+struct VoteRegs {
+    uint4 v;                           /* 4 entries of the chunk */
+    uint32_t th;                       /* theta_v of hit h0 + lane */
+    __device__ __forceinline__ void load(const oslamk_vote_args &a, const uint4 *hits, const VoteStep &d, int lane)
     {
         const uint32_t e = d.off + 4u * (uint32_t)lane;
         if (e < d.ln) v = *reinterpret_cast<const uint4 *>(&a.ent.e4[(size_t)d.st + e]);
+        if ((uint32_t)lane < d.R) th = hits[d.h0 + (uint32_t)lane].w;
     }
-    /* All hits of the run vote with this chunk.  cs2v / fv / vyv / vzv: per-lane data of the
-     * wave's 64 hits (cs2 = (theta_v + 15 bins) mod one turn; fv = theta_v is the marker).
-     * Votes that need the reference's float sequence are queued (their operands are a dependent
-     * gather that would stall the stream) and evaluated 64 at a time by SlowQueue::flush. */
-    __device__ __forceinline__ void vote(const oslamk_vote_args &a, uint32_t *acc, const uint32_t *tbl,
-                                         SlowQueue &sq, const ChunkDesc &d, int lane, uint32_t cs2v, bool fv,
-                                         float vyv, float vzv) const
+    /* Votes of hit i that are near a bin edge (or all of them: forced) are queued for re-evaluation
+     * and their lanes redirected to the trash word. */
+    __device__ __forceinline__ static void queue_edge_votes(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
+                                                            const uint32_t *tbl, SlowQueue &sq, uint32_t entry0,
+                                                            uint32_t hit, int rem, bool forced,
+                                                            const uint32_t (&pos)[4], uint32_t (&addr)[4], int lane)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long nm = __ballot(rem > j && (forced || pos[j] < PC_T24_EDGE));
+            if (nm) {
+                if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, hits, acc, tbl, lane);
+                sq.push(nm, lane, entry0 + j, hit);
+                if ((nm >> lane) & 1ull) addr[j] = 4u * (ACC_TRASH + (uint32_t)lane);
+            }
+        }
+    }
+    __device__ __forceinline__ void vote(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
+                                         const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
     {
         const uint32_t e = d.off + 4u * (uint32_t)lane;
         const int rem = (int)d.ln - (int)e;                  /* entries of this lane that exist */
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t am[4], row[4];
+        const uint32_t csmv = pc_vote_base_t24(th);
+        uint32_t wa[4], rowb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            am[j] = w[j] & 0x3fffffu;
-            /* accumulator row of the entry, or the lane's trash word (then the bin must add 0) */
-            row[j] = rem > j ? (w[j] >> 22) << 5 : ACC_TRASH + (uint32_t)lane;
+            wa[j] = w[j] << 2;
+            /* byte offset of the entry's accumulator row, or of the lane's trash word */
+            rowb[j] = rem > j ? (w[j] >> 22) << 7 : 4u * (ACC_TRASH + (uint32_t)lane);
         }
-        for (int i = 0; i < d.run; i++) {
-            const int li = d.head + i;
-            const uint32_t cs2 = readlane_u(cs2v, li);
-            const bool forced = d.bforced || (readlane_u((uint32_t)fv, li) != 0);
-            uint32_t idx[4];
-            bool need[4];
-            bool any_need = false;
+        /* hits whose every vote is re-evaluated: all of them when the bucket holds a marker */
+        const unsigned long long fmask =
+            MODE == 0 ? (d.bforced ? ~0ull : __ballot((uint32_t)lane < d.R && th == PC_T22_FORCE)) : 0ull;
+#if defined(EXP_NOATOM)
+        uint32_t sink = 0;
+#endif
+        for (int i = d.i0; i < d.i1; i++) {
+            const uint32_t csm = readlane_u(csmv, i);
+            uint32_t tm[4], addr[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t t = cs2 - am[j];                    /* in (-turn, turn) */
-                const uint32_t t_wrapped = t + PC_Q17_TURN;
-                t = t < t_wrapped ? t : t_wrapped;           /* unsigned min = mod one turn */
-                idx[j] = row[j] + (rem > j ? t >> 17 : 0u);
-                /* within PC_Q17_MARGIN of a bin edge (either side)?  forced: every vote of the bucket */
-                need[j] = MODE == 0 && rem > j &&
-                          (forced || ((t - PC_Q17_MARGIN) & (PC_Q17_ONE - 1u)) >= PC_Q17_ONE - 2u * PC_Q17_MARGIN);
-                any_need = any_need || need[j];
+                tm[j] = csm - wa[j];
+                addr[j] = rowb[j] + (mul24_hi_7680(tm[j]) << 2);
             }
-            if (MODE == 0 && __any(any_need)) {
-                const float vy = readlane_f(vyv, li), vz = readlane_f(vzv, li);
+            if (MODE == 0) {
+                /* position inside the (shifted) bin, in 2^-32 bin: below PC_T24_EDGE = within the margin
+                 * of an edge.  One compare of the smallest of the four decides whether anything is
+                 * queued; lanes past the bucket end only ever cause a look that finds nothing. */
+                uint32_t pos[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const unsigned long long nm = __ballot(need[j]);
-                    if (nm) {
-                        sq.push(nm, need[j], lane, d.st + e + j, w[j] >> 22, vy, vz);
-                        if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, acc, tbl, lane);
-                        if (need[j]) idx[j] = ACC_TRASH + (uint32_t)lane;
-                    }
-                }
+                for (int j = 0; j < 4; j++) pos[j] = mul24_lo_7680(tm[j]);
+                const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
+                const bool forced = (fmask >> i) & 1ull;
+                if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
+                    queue_edge_votes(a, hits, acc, tbl, sq, d.st + e, d.h0 + (uint32_t)i, rem, forced, pos, addr, lane);
             }
+#if defined(EXP_NOATOM)
+            sink ^= addr[0] ^ addr[1] ^ addr[2] ^ addr[3];
+#else
 #pragma unroll
-            for (int j = 0; j < 4; j++) atomicAdd(&acc[idx[j]], 1u);
+            for (int j = 0; j < 4; j++) {
+#if defined(EXP_NOCONF)
+                addr[j] = (addr[j] & 0x10000u) + 4u * (uint32_t)lane + 256u * j;
+#endif
+                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(acc) + addr[j]), 1u);
+            }
+#endif
         }
+#if defined(EXP_NOATOM)
+        if (sink == 0x12345u) acc[lane] = sink;
+#endif
     }
 };
 
@@ -416,7 +482,7 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
                     const float vy = pc_row_dot(rows, x, y, z);     /* kernel.cu:334-336 */
                     const float vz = pc_row_dot(rows + 4, x, y, z);
                     rec = make_uint4(key, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz),
-                                     pc_angle_q17(vy, vz));
+                                     pc_angle_t22(vy, vz));
                 }
             }
         }
@@ -435,30 +501,43 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 
 /* Sorts the hit list of each reference point of the batch by key, so that hits that share a
  * bucket are adjacent (on the bench scene a bucket is hit 3.8 times per reference point on
- * average; streaming it once per run cuts the entry traffic 4.7x).  One workgroup per reference
- * point: bitonic sort of (key << 32 | index) in LDS, then the records are gathered into the
- * second list.  Lists longer than SORT_MAX stay in arrival order (still correct, runs are just
- * short). */
+ * average; streaming it once per run cuts the entry traffic 4.7x), and writes the run list the
+ * vote kernel works from: runs[u] = {key, index of the run's first hit}; a run also ends at every
+ * multiple of 64 hits, so a run piece is at most one hit per lane; runs[n_runs] = {0, n_hits}.
+ * One workgroup per reference point: bitonic sort of (key << 32 | index) in LDS, then the records
+ * are gathered into the second list.  Lists longer than SORT_MAX stay in arrival order with one
+ * run per hit (still correct, the buckets are just streamed once per hit). */
 #define SORT_MAX 16384
-__global__ __launch_bounds__(1024) void k_sort_hits(oslamk_vote_args a)
+#define SORT_THREADS 1024
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 {
     __shared__ unsigned long long buf[SORT_MAX];
-    const int ref_local = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t s_part[SORT_THREADS / WAVE];
+    const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const uint32_t n = a.hit_count[ref_local];
     const uint4 *src = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
     uint4 *dst = reinterpret_cast<uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
+    uint2 *runs = reinterpret_cast<uint2 *>(a.runs) + (size_t)ref_local * (a.hit_stride + 1);
     if (n > SORT_MAX) {
-        for (uint32_t i = tid; i < n; i += 1024) dst[i] = src[i];
+        for (uint32_t i = tid; i < n; i += SORT_THREADS) {
+            const uint4 r = src[i];
+            dst[i] = r;
+            runs[i] = make_uint2(r.x, i);
+        }
+        if (tid == 0) {
+            runs[n] = make_uint2(0u, n);
+            a.run_count[ref_local] = n;
+        }
         return;
     }
     uint32_t P = 64;
     while (P < n) P <<= 1;
-    for (uint32_t i = tid; i < P; i += 1024)
+    for (uint32_t i = tid; i < P; i += SORT_THREADS)
         buf[i] = i < n ? ((unsigned long long)src[i].x << 32) | i : ~0ull;
     __syncthreads();
     for (uint32_t k = 2; k <= P; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < P / 2; t += 1024) {
+            for (uint32_t t = tid; t < P / 2; t += SORT_THREADS) {
                 /* t-th compare-exchange of this pass: partner indices differ in bit j */
                 const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
                 const unsigned long long x = buf[lo], y = buf[hi];
@@ -468,138 +547,237 @@ __global__ __launch_bounds__(1024) void k_sort_hits(oslamk_vote_args a)
             __syncthreads();
         }
     }
-    for (uint32_t i = tid; i < n; i += 1024) dst[i] = src[(uint32_t)buf[i]];
+    for (uint32_t i = tid; i < n; i += SORT_THREADS) dst[i] = src[(uint32_t)buf[i]];
+
+    /* run heads: thread t owns sorted positions [t*per, (t+1)*per) */
+    const uint32_t per = SORT_MAX / SORT_THREADS, i0 = (uint32_t)tid * per;
+    uint32_t heads = 0, cnt = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = i0 + k;
+        if (i < n) {
+            const bool head = (i & (WAVE - 1)) == 0 || (uint32_t)(buf[i] >> 32) != (uint32_t)(buf[i - 1] >> 32);
+            heads |= (uint32_t)head << k;
+            cnt += head;
+        }
+    }
+    uint32_t incl = cnt;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += up;
+    }
+    if (lane == WAVE - 1) s_part[wid] = incl;
+    __syncthreads();
+    uint32_t pos = incl - cnt, total = 0;
+    for (int w = 0; w < SORT_THREADS / WAVE; w++) {
+        const uint32_t v = s_part[w];
+        if (w < wid) pos += v;
+        total += v;
+    }
+    for (uint32_t k = 0; k < per; k++)
+        if ((heads >> k) & 1u) runs[pos++] = make_uint2((uint32_t)(buf[i0 + k] >> 32), i0 + k);
+    if (tid == 0) {
+        runs[total] = make_uint2(0u, n);
+        a.run_count[ref_local] = total;
+    }
 }
 
 /* One workgroup = one (scene reference point, model slice).
  * LDS: acc[1024][32] u32 = 128 KiB (one workgroup per CU, 16 waves).
  * ComputeUniqueVotes (model.cu:95-171) without the vote list: K3/K4
  * (kernel.cu:480-554) accumulate straight into acc, and the sort/histogram/
- * threshold of model.cu:148-170 becomes the scan at the end. */
+ * threshold of model.cu:148-170 becomes the scan at the end.
+ *
+ * The runs of the reference point are taken VOTE_RND at a time.  Per round: one thread per run
+ * probes the slice table (one 16-byte slot load per probe) and writes the item {bucket start,
+ * length, first hit, hits} to LDS; a unit of work is one (chunk of 256 entries, hit) pair, i.e.
+ * four LDS atomics per lane; a prefix sum over the items' units splits the round into 16 equal
+ * ranges, one per wave, so the waves finish together whatever the bucket lengths are.  A wave
+ * walks its range chunk by chunk with the next chunk's loads in flight. */
+#define VOTE_RND 512
 template <int MODE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 {
-    __shared__ uint32_t acc[ACC_CELLS + WAVE];      /* + one trash word per lane */
+    __shared__ __attribute__((aligned(16))) uint32_t acc[ACC_CELLS + ACC_TRASH_WORDS];
+    __shared__ uint4 s_item[VOTE_RND];
+    __shared__ unsigned long long s_pref[VOTE_RND + 1];
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
-    __shared__ unsigned long long s_wave64[2][VOTE_THREADS / WAVE];
+    __shared__ unsigned long long s_wave64[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_g, s_lmax, s_base;
     __shared__ uint32_t s_tbl[32];
-    __shared__ uint4 s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SlowQueue::CAP : 1];
+    __shared__ unsigned long long s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SlowQueue::CAP : 1];
 
-    typedef Chunk<MODE> CH;
+    typedef VoteRegs<MODE> VR;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const int n_slices = a.table.n_slices;
     const int ref_local = (int)(blockIdx.x / n_slices);
     const int ref_ord = a.first_ref + ref_local;
     const int slice = (int)(blockIdx.x % n_slices);
     const uint32_t r = a.ref_idx[ref_ord];
-    const uint32_t n_hits = a.hit_count[ref_local];
+    const uint32_t n_runs = a.run_count[ref_local];
     const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
+    const uint2 *runs = reinterpret_cast<const uint2 *>(a.runs) + (size_t)ref_local * (a.hit_stride + 1);
 
-    for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) acc[c] = 0;
+    for (int c = tid; c < ACC_CELLS / 4; c += VOTE_THREADS) reinterpret_cast<uint4 *>(acc)[c] = make_uint4(0, 0, 0, 0);
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
 
     const oslamk_slot *tab = a.table.slots + (size_t)slice * a.table.cap;
     const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
     const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
-    unsigned long long my_hits = 0, my_votes = 0;
+    unsigned long long my_votes = 0;
     SlowQueue sq;
     sq.q = s_slow + (MODE == 0 ? wid * SlowQueue::CAP : 0);
     sq.n = 0;
+#ifdef VOTE_PROF
+    const long long pt0 = clock64();
+    long long pt_busy = 0, pt_items = 0;
+#endif
     __syncthreads();
 
-    for (uint32_t base = 0; base < n_hits; base += VOTE_THREADS) {
-        const uint32_t h = base + tid;
-        const bool have = h < n_hits;
-        uint32_t key = 0, cs2v = 0;
-        bool fv = false;
-        float vyv = 0.0f, vzv = 0.0f;
-        if (have) {
-            const uint4 rec = hits[h];
-            uint32_t c = rec.w + 15u * PC_Q17_ONE;
-            key = rec.x;
-            vyv = __builtin_bit_cast(float, rec.y);
-            vzv = __builtin_bit_cast(float, rec.z);
-            fv = rec.w == PC_Q17_FORCE;
-            cs2v = c >= PC_Q17_TURN ? c - PC_Q17_TURN : c;
-            if (slice == 0) my_hits += 1;
-        }
-        /* runs of equal keys inside this wave's 64 hits: the first lane of a run probes the
-         * slice table; the run ends where the next one starts (or at the last hit) */
-        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, WAVE);
-        const bool is_head = have && (lane == 0 || key != prev);
-        const unsigned long long heads = __ballot(is_head), haves = __ballot(have);
-        uint32_t start = 0, len = 0, bflag = 0;
-        int run = 0;
-        if (is_head) {
-            const unsigned long long later = heads & ~((2ull << lane) - 1ull);   /* heads above this lane */
-            const int end = later ? __ffsll((long long)later) - 1 : __popcll(haves);
-            run = end - lane;
-            uint32_t slot = slot_of(key, shift);
-            for (uint32_t probe = 0; probe <= mask; probe++) {
-                const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
-                if (sv.x == key) {
-                    start = sv.y;
-                    len = sv.z;
-                    bflag = sv.w >> 31;                       /* the bucket holds an entry with the marker */
-                    my_votes += (unsigned long long)len * (unsigned)run;
-                    break;
-                }
-                if (sv.x == 0) break;
-                slot = (slot + 1) & mask;
-            }
-        }
-        /* wave-cooperative sweep: all 64 lanes stream one bucket at a time in chunks of 256
-         * entries, every hit of the run votes with the chunk, and the next chunk's load
-         * (possibly of the next bucket) is in flight meanwhile.  Generator state is wave-uniform. */
-        unsigned long long todo = __ballot(len > 0);
-        ChunkDesc g;                       /* the next chunk to hand out */
-        g.valid = todo != 0;
-        auto open_bucket = [&](int l) {
-            g.st = readlane_u(start, l);
-            g.ln = readlane_u(len, l);
-            g.head = l;
-            g.run = (int)readlane_u((uint32_t)run, l);
-            g.bforced = readlane_u(bflag, l) != 0;
-            g.off = 0;
-        };
-        if (g.valid) open_bucket(__ffsll((long long)todo) - 1);
-        auto next_chunk = [&]() -> ChunkDesc {
-            const ChunkDesc out = g;
-            if (g.valid) {
-                g.off += 4 * WAVE;
-                if (g.off >= g.ln) {
-                    todo &= todo - 1;
-                    if (todo) open_bucket(__ffsll((long long)todo) - 1);
-                    else g.valid = false;
+    for (uint32_t r0 = 0; r0 < n_runs; r0 += VOTE_RND) {
+        /* ---- items of this round and the prefix sum of their units ---- */
+#ifdef VOTE_PROF
+        const long long pt_r = clock64();
+#endif
+        unsigned long long units = 0;
+        if (tid < VOTE_RND) {
+            uint4 it = make_uint4(0, 0, 0, 0);
+            const uint32_t u = r0 + (uint32_t)tid;
+            if (u < n_runs) {
+                const uint2 rr = runs[u];
+                const uint32_t R = runs[u + 1].y - rr.y;
+                uint32_t slot = slot_of(rr.x, shift);
+                for (uint32_t probe = 0; probe <= mask; probe++) {
+                    const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
+                    if (sv.x == rr.x) {
+                        /* sv.w bit 31: the bucket holds an entry with the marker */
+                        it = make_uint4(sv.y, sv.z | (sv.w & 0x80000000u), rr.y, R);
+                        units = (unsigned long long)((sv.z + 255u) >> 8) * R;
+                        my_votes += (unsigned long long)sv.z * R;
+#ifdef VOTE_PROF
+                        {
+                            const int cls = sv.z <= 16 ? 0 : sv.z <= 64 ? 1 : sv.z <= 256 ? 2 : sv.z <= 1024 ? 3 : 4;
+                            atomicAdd(&a.counters->prof[4 + cls], units);                       /* units */
+                            atomicAdd(&a.counters->prof[9 + cls], (unsigned long long)sv.z * R); /* votes */
+                            atomicAdd(&a.counters->prof[14], 1ull);                              /* items */
+                            atomicAdd(&a.counters->prof[15], (unsigned long long)((sv.z + 255u) >> 8)); /* chunk loads */
+                        }
+#endif
+                        break;
+                    }
+                    if (sv.x == 0) break;
+                    slot = (slot + 1) & mask;
                 }
             }
-            return out;
-        };
-        /* VOTE_PIPE chunks are in flight ahead of the one being voted */
-        ChunkDesc d[VOTE_PIPE];
-        CH c[VOTE_PIPE];
-#pragma unroll
-        for (int i = 0; i < VOTE_PIPE; i++) {
-            d[i] = next_chunk();
-            if (d[i].valid) c[i].load(a, d[i], lane);
+            s_item[tid] = it;
         }
-        while (d[0].valid) {
-            const CH cur = c[0];
-            const ChunkDesc dc = d[0];
-#pragma unroll
-            for (int i = 0; i + 1 < VOTE_PIPE; i++) {
-                c[i] = c[i + 1];
-                d[i] = d[i + 1];
+        unsigned long long incl = units;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == WAVE - 1) s_wave64[wid] = incl;
+        __syncthreads();
+        if (tid < VOTE_RND) {
+            unsigned long long before = 0;
+            for (int w = 0; w < wid; w++) before += s_wave64[w];
+            s_pref[tid] = before + incl - units;
+            if (tid == VOTE_RND - 1) s_pref[VOTE_RND] = before + incl;
+        }
+        __syncthreads();
+
+#ifdef VOTE_PROF
+        pt_items += clock64() - pt_r;
+#endif
+        /* ---- this wave's share of the round ---- */
+        const unsigned long long total = uni_u64(s_pref[VOTE_RND]);
+        const uint32_t wu = uni_u32((uint32_t)wid);
+        const unsigned long long lo = (total * wu) >> 4, hi = (total * (wu + 1u)) >> 4;
+        if (hi > lo) {
+#ifdef VOTE_PROF
+            const long long pt_a = clock64();
+#endif
+            /* the item that holds unit lo: the last one whose prefix is <= lo */
+            int il = 0, ih = VOTE_RND;
+            while (ih - il > 1) {
+                const int mid = (il + ih) >> 1;
+                if (s_pref[mid] <= lo) il = mid; else ih = mid;
             }
-            d[VOTE_PIPE - 1] = next_chunk();
-            if (d[VOTE_PIPE - 1].valid) c[VOTE_PIPE - 1].load(a, d[VOTE_PIPE - 1], lane);
-            cur.vote(a, acc, s_tbl, sq, dc, lane, cs2v, fv, vyv, vzv);
+            /* generator state, wave-uniform */
+            int item = (int)uni_u32((uint32_t)il);
+            unsigned long long remaining = hi - lo;
+            uint32_t g_st, g_ln, g_h0, g_R, g_C, g_c, g_i0;
+            bool g_bf;
+            auto open_item = [&](int k) {
+                const uint4 it = s_item[k];
+                g_st = uni_u32(it.x);
+                const uint32_t lf = uni_u32(it.y);
+                g_ln = lf & 0x7fffffffu;
+                g_bf = (lf >> 31) != 0;
+                g_h0 = uni_u32(it.z);
+                g_R = uni_u32(it.w);
+                g_C = (g_ln + 255u) >> 8;
+            };
+            open_item(item);
+            {
+                const uint32_t o = uni_u32((uint32_t)(lo - s_pref[item]));
+                g_c = o / g_R;
+                g_i0 = o - g_c * g_R;
+            }
+            auto next_step = [&]() -> VoteStep {
+                VoteStep d;
+                d.valid = remaining != 0;
+                d.st = g_st; d.off = g_c << 8; d.ln = g_ln; d.h0 = g_h0; d.R = g_R; d.bforced = g_bf;
+                d.i0 = (int)g_i0;
+                uint32_t nh = g_R - g_i0;
+                if ((unsigned long long)nh > remaining) nh = (uint32_t)remaining;
+                d.i1 = (int)(g_i0 + nh);
+                if (d.valid) {
+                    remaining -= nh;
+                    g_i0 = 0;
+                    g_c++;
+                    if (g_c == g_C && remaining != 0) {
+                        do {                       /* items without units: the key is not in this slice */
+                            item++;
+                            if (item >= VOTE_RND) break;     /* cannot happen: the prefix sums cover `remaining` */
+                            open_item(item);
+                        } while (g_C == 0 || g_R == 0);
+                        if (item >= VOTE_RND) remaining = 0;
+                        g_c = 0;
+                    }
+                }
+                return d;
+            };
+            VoteStep d0 = next_step();
+            VR c0;
+            c0.load(a, hits, d0, lane);
+            while (d0.valid) {
+                const VoteStep d1 = next_step();
+                VR c1 = c0;
+                if (d1.valid) c1.load(a, hits, d1, lane);
+                c0.vote(a, hits, acc, s_tbl, sq, d0, lane);
+                c0 = c1;
+                d0 = d1;
+            }
+#ifdef VOTE_PROF
+            pt_busy += clock64() - pt_a;
+#endif
         }
+        __syncthreads();            /* the next round rewrites the items */
     }
-    if (MODE == 0) sq.flush(a, acc, s_tbl, lane);
+    if (MODE == 0) sq.flush(a, hits, acc, s_tbl, lane);
+#ifdef VOTE_PROF
+    const long long pt1 = clock64();
+#endif
     __syncthreads();
+#ifdef VOTE_PROF
+    const long long pt2 = clock64();
+    if (lane == 0) {
+        atomicAdd(&a.counters->prof[0], (unsigned long long)(pt1 - pt0));
+        atomicAdd(&a.counters->prof[1], (unsigned long long)pt_items);
+        atomicAdd(&a.counters->prof[3], (unsigned long long)pt_busy);
+    }
+#endif
 
     /* ---- peak extraction: local max, non-empty cells, emission ---- */
     uint32_t lmax = 0, nz = 0;
@@ -610,23 +788,21 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     }
     lmax = wave_max_u32(lmax);
     nz = wave_sum_u32(nz);
-    my_hits = wave_sum_u64(my_hits);
     my_votes = wave_sum_u64(my_votes);
     if (lane == 0) {
         s_wave[wid] = lmax;
         s_wave2[wid] = nz;
-        s_wave64[0][wid] = my_hits;
-        s_wave64[1][wid] = my_votes;
+        s_wave64[wid] = my_votes;
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t m = 0, n = 0;
-        unsigned long long h = 0, v = 0;
+        /* hits are counted once per reference point */
+        unsigned long long h = slice == 0 ? (unsigned long long)runs[n_runs].y : 0ull, v = 0;
         for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
             m = s_wave[w] > m ? s_wave[w] : m;
             n += s_wave2[w];
-            h += s_wave64[0][w];
-            v += s_wave64[1][w];
+            v += s_wave64[w];
         }
         uint32_t g = a.fixed_gmax;
         if (g == 0) {
@@ -687,6 +863,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             }
         }
     }
+#ifdef VOTE_PROF
+    if (lane == 0) atomicAdd(&a.counters->prof[2], (unsigned long long)(clock64() - pt2));
+#endif
 }
 
 /* --------------------------------------------------------------------------

@@ -138,57 +138,67 @@ PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const 
 /* ---- quantised-angle voting -------------------------------------------------
  * In exact arithmetic alpha = theta_v - theta_u with theta = atan2(z, y) of the
  * transformed second points (Drost).  A model pair stores theta_u, a scene pair
- * theta_v, both as (theta + pi)/D in units of 2^-17 bin; their difference gives
- * bin and position inside the bin with integer arithmetic.  The float rounding of
- * the reference's own sequence (cross/dot products, atan2f, + pi, quantisation)
- * moves alpha by < 2e-5 bin against this value (bound in DESIGN.md), so whenever
- * the position is further than PC_Q17_MARGIN = 2^-12 bin from a bin edge the bin
- * is the reference's; otherwise the vote is re-evaluated with pc_alpha_bin_table.
+ * theta_v, both as theta + pi in units of 2^-22 turn (7.2e-6 bin), so their
+ * difference wraps by itself and
+ *     t24 = 4 * ((theta_v - theta_u + half a turn) mod one turn)        (24 bits)
+ *     t24 * 7680 = bin * 2^32 + position inside the bin * 2^32          (7680 = 30 * 2^8)
+ * i.e. the bin is v_mul_hi_u32_u24(t24, 7680) and the position v_mul_u32_u24(t24, 7680).
+ * The float rounding of the reference's own sequence (cross/dot products, atan2f,
+ * + pi, quantisation) moves alpha by < 2e-5 bin against this value (bound in
+ * DESIGN.md), so whenever the position is further than the margin (2.3e-4 bin)
+ * from a bin edge the bin is the reference's; otherwise the vote is re-evaluated
+ * with pc_alpha_bin_table.  The margin is added to t24 first, so that one unsigned
+ * compare of the position finds both sides of an edge; the bin read from the
+ * shifted value is only used when the vote is not re-evaluated, where it is the
+ * unshifted one.
  * Result: identical bins at a fraction of the arithmetic and 4 bytes per vote. */
-#define PC_Q17_ONE 131072u                    /* 2^17 units per bin */
-#define PC_Q17_TURN (30u * PC_Q17_ONE)       /* one full turn */
-#define PC_Q17_MARGIN 32u                     /* 2^-12 bin */
-#define PC_Q17_FORCE 0x3fffffu                /* "always re-evaluate" marker (fits 22 bits, > PC_Q17_TURN) */
+#define PC_T22_TURN 4194304u                  /* 2^22 units per turn */
+#define PC_T24_SCALE 7680u                    /* 30 bins * 2^8 */
+#define PC_T24_MARGIN 128u                    /* in t24 units: 128 * 30 / 2^24 = 2.3e-4 bin */
+#define PC_T24_EDGE (2u * PC_T24_MARGIN * PC_T24_SCALE)   /* position (2^-32 bin) below which a shifted vote is near an edge */
+#define PC_T22_FORCE 0xffffffffu              /* "always re-evaluate" marker */
+#define PC_T22_PER_RAD 667544.214430109f      /* 2^22 / (2 pi) */
 
-/* (atan2(z, y) + pi) / D in units of 2^-17 bin, in [0, PC_Q17_TURN]; PC_Q17_FORCE when the
+/* (atan2(z, y) + pi) in units of 2^-22 turn, in [0, PC_T22_TURN); PC_T22_FORCE when the
  * vector is zero, not finite or outside 2^-40..2^40, where the products of kernel.cu:84,52
  * could overflow or lose the vector to underflow and the error bound would not hold */
-PM_HD uint32_t pc_angle_q17(float y, float z)
+PM_HD uint32_t pc_angle_t22(float y, float z)
 {
     const uint32_t by = PM_BITS_F2U(y) & 0x7fffffffu, bz = PM_BITS_F2U(z) & 0x7fffffffu;
     const uint32_t e = (by > bz ? by : bz) >> 23;
-    const float t = (pm_atan2f(z, y) + PM_PI_F) / PM_D_ANGLE;
-    const float q = __builtin_rintf(t * 131072.0f);
-    if (e < 87u || e > 167u || !(q >= 0.0f && q <= 3932160.0f)) return PC_Q17_FORCE;
-    return (uint32_t)q;
+    const float q = __builtin_rintf((pm_atan2f(z, y) + PM_PI_F) * PC_T22_PER_RAD);
+    if (e < 87u || e > 167u || !(q >= 0.0f && q <= 4194304.0f)) return PC_T22_FORCE;
+    return (uint32_t)q & (PC_T22_TURN - 1u);
 }
 
-/* position of alpha + pi on the turn: ((theta_v - theta_u) + pi) mod 2 pi */
-PM_HD uint32_t pc_turn_q17(uint32_t cs_q17, uint32_t am_q17)
+/* what a scene pair contributes to every vote of its reference point: 4 * (theta_v + half a
+ * turn) + margin; only the low 24 bits matter */
+PM_HD uint32_t pc_vote_base_t24(uint32_t theta_v_t22)
 {
-    uint32_t t = cs_q17 + 15u * PC_Q17_ONE + PC_Q17_TURN - am_q17;   /* in (0, 75*2^17] */
-    t = t >= PC_Q17_TURN ? t - PC_Q17_TURN : t;
-    t = t >= PC_Q17_TURN ? t - PC_Q17_TURN : t;
-    return t;
+    return ((theta_v_t22 + PC_T22_TURN / 2u) << 2) + PC_T24_MARGIN;
 }
 
-/* 1 when the quantised position cannot decide the bin: too close to a bin edge, or one of
- * the two angles carries the marker */
-PM_HD int pc_turn_needs_exact(uint32_t t, uint32_t cs_q17, uint32_t am_q17)
-{
-    const uint32_t f = t & (PC_Q17_ONE - 1u);
-    return f < PC_Q17_MARGIN || f >= PC_Q17_ONE - PC_Q17_MARGIN || cs_q17 == PC_Q17_FORCE ||
-           am_q17 == PC_Q17_FORCE;
-}
+/* low 24 bits of a, times b (< 2^24): the two halves of v_mul_u32_u24 / v_mul_hi_u32_u24 */
+PM_HD uint32_t pc_mul24_lo(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xffffffu) * b); }
+PM_HD uint32_t pc_mul24_hi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xffffffu) * b) >> 32); }
 
 /* the reference's bin from the stored quantities (host-side statement of what the
- * vote kernel does; used by the CPU check of the scheme) */
+ * vote kernel does; used by the CPU check of the scheme).  *needs_exact (optional) reports
+ * whether the vote had to be re-evaluated, *pos_bins the unshifted quantised position. */
+PM_HD unsigned pc_alpha_bin_hybrid_ex(float uy, float uz, float vy, float vz, const uint32_t *tbl,
+                                      int *needs_exact, double *pos_bins)
+{
+    const uint32_t cs = pc_angle_t22(vy, vz), am = pc_angle_t22(uy, uz);
+    const uint32_t tm = pc_vote_base_t24(cs) - (am << 2);
+    const int slow = cs == PC_T22_FORCE || am == PC_T22_FORCE || pc_mul24_lo(tm, PC_T24_SCALE) < PC_T24_EDGE;
+    if (needs_exact) *needs_exact = slow;
+    if (pos_bins) *pos_bins = (double)((tm - PC_T24_MARGIN) & 0xffffffu) * 30.0 / 16777216.0;
+    if (slow) return pc_alpha_bin_table(uy, uz, vy, vz, tbl);
+    return pc_mul24_hi(tm, PC_T24_SCALE);
+}
 PM_HD unsigned pc_alpha_bin_hybrid(float uy, float uz, float vy, float vz, const uint32_t *tbl)
 {
-    const uint32_t cs = pc_angle_q17(vy, vz), am = pc_angle_q17(uy, uz);
-    const uint32_t t = pc_turn_q17(cs, am);
-    if (pc_turn_needs_exact(t, cs, am)) return pc_alpha_bin_table(uy, uz, vy, vz, tbl);
-    return t >> 17;
+    return pc_alpha_bin_hybrid_ex(uy, uz, vy, vz, tbl, 0, 0);
 }
 
 #endif /* OSLAM_PPF_CORE_H */

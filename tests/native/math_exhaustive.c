@@ -30,7 +30,7 @@ static uint64_t splitmix(uint64_t *s)
     return z ^ (z >> 31);
 }
 
-static int cs_ok(float y, float z) { return pc_angle_q17(y, z) != PC_Q17_FORCE; }
+static int cs_ok(float y, float z) { return pc_angle_t22(y, z) != PC_T22_FORCE; }
 
 static int same(float a, float b)
 {
@@ -166,12 +166,13 @@ int main(int argc, char **argv)
             if (hybrid && b != 255u && (i & 7) != 7 && cs_ok(uy, uz) && cs_ok(vy, vz)) {
                 /* distance (in bins, on the circle) between the quantised position and the
                  * reference's alpha + pi: the quantity the margin has to cover */
-                uint32_t cs = pc_angle_q17(vy, vz), am = pc_angle_q17(uy, uz);
-                uint32_t t = pc_turn_q17(cs, am);
-                double d = fabs((double)t / 131072.0 - (double)al / (double)PM_D_ANGLE);
+                int ne = 0;
+                double pos = 0.0;
+                (void)pc_alpha_bin_hybrid_ex(uy, uz, vy, vz, &PC_ALPHA_THR[0][0], &ne, &pos);
+                double d = fabs(pos - (double)al / (double)PM_D_ANGLE);
                 if (d > 15.0) d = fabs(d - 30.0);
                 if (d > worst) worst = d;
-                slow += (uint64_t)pc_turn_needs_exact(t, cs, am);
+                slow += (uint64_t)ne;
             }
             if (a != b) {
                 bad++;
@@ -179,7 +180,7 @@ int main(int argc, char **argv)
             }
         }
         if (hybrid) printf("largest |quantised - reference| = %.3g bin (margin %.3g); re-evaluated %.4f%%\n", worst,
-                           (double)PC_Q17_MARGIN / 131072.0, 100.0 * (double)slow / (double)checked);
+                           (double)PC_T24_MARGIN * 30.0 / 16777216.0, 100.0 * (double)slow / (double)checked);
     } else {
         return 2;
     }
