@@ -453,7 +453,7 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
 
 /* Scratch for the hit lists of one batch of reference points: one pool per device, shared by all
  * models (it is only live inside an align call; like the reference, calls on one device are not
- * re-entrant).  Up to OSLAM_SCRATCH_GIB (default 8) GiB, at least one reference point's worth. */
+ * re-entrant).  Up to OSLAM_SCRATCH_GIB (default 16) GiB, at least one reference point's worth. */
 #define MAX_DEVICES 64
 typedef struct {
     oslamk_hit *hits;
@@ -466,9 +466,12 @@ static scratch_pool g_pool[MAX_DEVICES];
 static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratch_pool **pool_out, int *batch_out)
 {
     int rc = OSLAM_OK;
-    /* per reference point: hits in arrival order + sorted by key (16 B each) + run list (8 B each, + end marker) */
-    const size_t per_ref = 2 * (size_t)s->c.n * sizeof(oslamk_hit) + ((size_t)s->c.n + 1) * 2 * sizeof(uint32_t);
-    size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)8 << 30;
+    /* per reference point: hits in arrival order + sorted by key (16 B each), run list (8 B each, + end
+     * marker), and per slice the vote workgroup's items (16 B per run) + one running sum per 64 items */
+    const size_t S = (size_t)s->c.n, nsl = (size_t)m->table.n_slices;
+    const size_t per_ref = 2 * S * sizeof(oslamk_hit) + (S + 1) * 2 * sizeof(uint32_t) +
+                           nsl * (S * 16 + (S / 64 + 1) * sizeof(unsigned long long));
+    size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)16 << 30;
     const char *env = getenv("OSLAM_SCRATCH_GIB");
     scratch_pool *p;
     size_t batch;
@@ -494,6 +497,24 @@ static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratc
     *batch_out = (int)batch;
 done:
     return rc;
+}
+
+/* the arrays of one batch inside the pool (sizes as in ensure_hit_scratch) */
+static void carve_scratch(oslamk_vote_args *a, const scratch_pool *pool, int batch, size_t S, size_t nsl)
+{
+    char *p = (char *)pool->hits;
+    a->hits = (oslamk_hit *)p;
+    p += (size_t)batch * S * sizeof(oslamk_hit);
+    a->hits_sorted = (oslamk_hit *)p;
+    p += (size_t)batch * S * sizeof(oslamk_hit);
+    a->items = (uint32_t *)p;
+    p += (size_t)batch * nsl * S * 16;
+    a->item_sums = (unsigned long long *)p;
+    p += (size_t)batch * nsl * (S / 64 + 1) * sizeof(unsigned long long);
+    a->runs = (uint32_t *)p;
+    a->hit_count = pool->hit_count;
+    a->run_count = pool->hit_count + pool->hit_count_cap;
+    a->hit_stride = S;
 }
 
 #define MAX_BATCH_EVENTS 64
@@ -530,8 +551,7 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
     a.hit_count = pool->hit_count;
     a.hit_stride = (size_t)s->c.n;
-    a.runs = (uint32_t *)(pool->hits + 2 * (size_t)batch * (size_t)s->c.n);
-    a.run_count = pool->hit_count + pool->hit_count_cap;
+    carve_scratch(&a, pool, batch, (size_t)s->c.n, (size_t)m->table.n_slices);
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
@@ -588,16 +608,10 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
         if (cnt->out_count > m->out_cap)
             return fail(OSLAM_E_LIMIT, "more accumulator peaks than params.max_cells");
     }
-    if (getenv("OSLAM_PROF"))
-        fprintf(stderr, "[oslam prof] wave cycles: to end of voting %llu, building items %llu, epilogue %llu, in vote steps %llu\n",
+    if (getenv("OSLAM_PROF"))      /* only a -DVOTE_PROF build fills these */
+        fprintf(stderr, "[oslam prof] k_vote wave cycles: to the end of voting %llu, to the barrier after it %llu, "
+                        "peak extraction %llu, inside vote steps %llu\n",
                 cnt->prof[0], cnt->prof[1], cnt->prof[2], cnt->prof[3]);
-    if (getenv("OSLAM_PROF")) {
-        int c;
-        for (c = 0; c < 5; c++)
-            fprintf(stderr, "[oslam prof] bucket class %d: units %llu votes %llu (lanes used %.3f)\n", c, cnt->prof[4 + c],
-                    cnt->prof[9 + c], cnt->prof[4 + c] ? (double)cnt->prof[9 + c] / (256.0 * (double)cnt->prof[4 + c]) : 0.0);
-        fprintf(stderr, "[oslam prof] items %llu chunk loads %llu\n", cnt->prof[14], cnt->prof[15]);
-    }
     *n_cells = cnt->out_count;
     if (*n_cells) {
         HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * *n_cells, hipMemcpyDeviceToHost));
@@ -921,8 +935,7 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
         a.hits = pool->hits;
         a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
         a.hit_count = pool->hit_count;
-        a.runs = (uint32_t *)(pool->hits + 2 * (size_t)batch * (size_t)s->c.n);
-        a.run_count = pool->hit_count + pool->hit_count_cap;
+        carve_scratch(&a, pool, batch, (size_t)s->c.n, (size_t)m->table.n_slices);
     }
     a.hit_stride = (size_t)s->c.n;
     HIPCHK(hipMemsetAsync(a.hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));

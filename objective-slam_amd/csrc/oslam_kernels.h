@@ -71,7 +71,7 @@ typedef struct oslamk_counters {
     uint32_t gmax;
     uint32_t out_count;
     uint32_t pad[2];
-    unsigned long long prof[16]; /* -DVOTE_PROF builds: wave cycles to the end of voting / to the barrier / epilogue / in vote steps */
+    unsigned long long prof[4];   /* -DVOTE_PROF builds: k_vote wave cycles (end of voting, barrier, peak extraction, vote steps) */
 } oslamk_counters;
 
 typedef struct oslamk_cell {
@@ -130,6 +130,11 @@ typedef struct oslamk_vote_args {
      * of the run in hits_sorted}, u <= run_count[ref_local]; the last one is the end marker {0, hit_count} */
     uint32_t *runs;
     uint32_t *run_count;
+    /* scratch of the vote workgroups, one region per (ref_local, slice) = per workgroup:
+     * items[wg * hit_stride + k] = {bucket start, length | marker << 31, first hit, hits} (16 B) and
+     * item_sums[wg * (hit_stride / 64 + 1) + k / 64] = work units before item k, for k % 64 == 0 */
+    uint32_t *items;
+    unsigned long long *item_sums;
 } oslamk_vote_args;
 
 /* scene pair keys -> per-reference hit lists, for reference ordinals first_ref..+n_launch-1;

@@ -26,7 +26,7 @@
 
 #define WAVE 64
 #ifndef VOTE_PIPE
-#define VOTE_PIPE 1       /* chunks in flight ahead of the one being voted (1 measured best) */
+#define VOTE_PIPE 2       /* steps whose loads are in flight ahead of the one being voted */
 #endif
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
@@ -324,46 +324,52 @@ __device__ __forceinline__ void SlowQueue::flush(const oslamk_vote_args &a, cons
     n = 0;
 }
 
-/* One step of a wave (all fields wave-uniform): chunk `off` of the bucket [st, st+ln) voted by the
- * hits h0+i0 .. h0+i1-1 of the run (a run piece has at most 64 hits, one per lane). */
+/* One step of a wave (all fields wave-uniform): one chunk of a bucket voted by the hits
+ * i0 .. i1-1 of the run piece (at most 64 hits, one per lane). */
 struct VoteStep {
-    uint32_t st, off, ln, h0, R;
+    const uint32_t *chunk;             /* first entry of the chunk */
+    const uint4 *hit0;                 /* first hit of the run piece */
+    uint32_t left;                     /* entries from the chunk start to the bucket end (>= 1) */
+    uint32_t entry0;                   /* index of the chunk's first entry (for the re-evaluation queue) */
+    uint32_t hbase;                    /* index of the piece's first hit (same) */
+    uint32_t R;
     int i0, i1;
     bool bforced, valid;               /* bforced: the bucket holds an entry with the marker */
 };
 
 template <int MODE>
 struct VoteRegs {
-    uint4 v;                           /* 4 entries of the chunk */
-    uint32_t th;                       /* theta_v of hit h0 + lane */
-    __device__ __forceinline__ void load(const oslamk_vote_args &a, const uint4 *hits, const VoteStep &d, int lane)
+    uint4 v;                           /* 4 entries of the chunk: lane l holds entries 4l .. 4l+3 */
+    uint32_t th;                       /* theta_v of hit `lane` of the piece */
+    __device__ __forceinline__ void load(const VoteStep &d, int lane)
     {
-        const uint32_t e = d.off + 4u * (uint32_t)lane;
-        if (e < d.ln) v = *reinterpret_cast<const uint4 *>(&a.ent.e4[(size_t)d.st + e]);
-        if ((uint32_t)lane < d.R) th = hits[d.h0 + (uint32_t)lane].w;
+        if (4u * (uint32_t)lane < d.left) v = reinterpret_cast<const uint4 *>(d.chunk)[lane];
+        if ((uint32_t)lane < d.R) th = d.hit0[lane].w;
     }
     /* Votes of hit i that are near a bin edge (or all of them: forced) are queued for re-evaluation
      * and their lanes redirected to the trash word. */
     __device__ __forceinline__ static void queue_edge_votes(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
                                                             const uint32_t *tbl, SlowQueue &sq, uint32_t entry0,
-                                                            uint32_t hit, int rem, bool forced,
+                                                            uint32_t hit, uint32_t left, bool forced,
                                                             const uint32_t (&pos)[4], uint32_t (&addr)[4], int lane)
     {
+        uint32_t e = 4u * (uint32_t)lane;
+        asm volatile("" : "+v"(e));      /* keeps the compares below out of the vote loop's preamble */
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned long long nm = __ballot(rem > j && (forced || pos[j] < PC_T24_EDGE));
+            const unsigned long long nm = __ballot(e + j < left && (forced || pos[j] < PC_T24_EDGE));
             if (nm) {
                 if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, hits, acc, tbl, lane);
-                sq.push(nm, lane, entry0 + j, hit);
+                sq.push(nm, lane, entry0 + e + j, hit);
                 if ((nm >> lane) & 1ull) addr[j] = 4u * (ACC_TRASH + (uint32_t)lane);
             }
         }
     }
-    __device__ __forceinline__ void vote(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                         const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
+    /* FULL: all 256 entries of the chunk exist, no lane needs the trash word */
+    template <bool FULL>
+    __device__ __forceinline__ void vote_impl(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
+                                              const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
     {
-        const uint32_t e = d.off + 4u * (uint32_t)lane;
-        const int rem = (int)d.ln - (int)e;                  /* entries of this lane that exist */
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t24(th);
         uint32_t wa[4], rowb[4];
@@ -371,14 +377,12 @@ struct VoteRegs {
         for (int j = 0; j < 4; j++) {
             wa[j] = w[j] << 2;
             /* byte offset of the entry's accumulator row, or of the lane's trash word */
-            rowb[j] = rem > j ? (w[j] >> 22) << 7 : 4u * (ACC_TRASH + (uint32_t)lane);
+            rowb[j] = (w[j] >> 15) & 0x1ff80u;
+            if (!FULL) rowb[j] = 4u * (uint32_t)lane + j < d.left ? rowb[j] : 4u * (ACC_TRASH + (uint32_t)lane);
         }
         /* hits whose every vote is re-evaluated: all of them when the bucket holds a marker */
         const unsigned long long fmask =
-            MODE == 0 ? (d.bforced ? ~0ull : __ballot((uint32_t)lane < d.R && th == PC_T22_FORCE)) : 0ull;
-#if defined(EXP_NOATOM)
-        uint32_t sink = 0;
-#endif
+            MODE == 0 ? (d.bforced ? ~0ull : __ballot(th == PC_T22_FORCE) & ((2ull << (d.R - 1u)) - 1ull)) : 0ull;
         for (int i = d.i0; i < d.i1; i++) {
             const uint32_t csm = readlane_u(csmv, i);
             uint32_t tm[4], addr[4];
@@ -397,23 +401,18 @@ struct VoteRegs {
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
                 const bool forced = (fmask >> i) & 1ull;
                 if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
-                    queue_edge_votes(a, hits, acc, tbl, sq, d.st + e, d.h0 + (uint32_t)i, rem, forced, pos, addr, lane);
+                    queue_edge_votes(a, hits, acc, tbl, sq, d.entry0, d.hbase + (uint32_t)i, d.left, forced, pos, addr, lane);
             }
-#if defined(EXP_NOATOM)
-            sink ^= addr[0] ^ addr[1] ^ addr[2] ^ addr[3];
-#else
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-#if defined(EXP_NOCONF)
-                addr[j] = (addr[j] & 0x10000u) + 4u * (uint32_t)lane + 256u * j;
-#endif
+            for (int j = 0; j < 4; j++)
                 atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(acc) + addr[j]), 1u);
-            }
-#endif
         }
-#if defined(EXP_NOATOM)
-        if (sink == 0x12345u) acc[lane] = sink;
-#endif
+    }
+    __device__ __forceinline__ void vote(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
+                                         const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
+    {
+        if (d.left >= 4u * WAVE) vote_impl<true>(a, hits, acc, tbl, sq, d, lane);
+        else vote_impl<false>(a, hits, acc, tbl, sq, d, lane);
     }
 };
 
@@ -587,19 +586,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
  * (kernel.cu:480-554) accumulate straight into acc, and the sort/histogram/
  * threshold of model.cu:148-170 becomes the scan at the end.
  *
- * The runs of the reference point are taken VOTE_RND at a time.  Per round: one thread per run
- * probes the slice table (one 16-byte slot load per probe) and writes the item {bucket start,
- * length, first hit, hits} to LDS; a unit of work is one (chunk of 256 entries, hit) pair, i.e.
- * four LDS atomics per lane; a prefix sum over the items' units splits the round into 16 equal
- * ranges, one per wave, so the waves finish together whatever the bucket lengths are.  A wave
+ * Phase 1, all threads: one thread per run of the reference point probes the slice table (one
+ * 16-byte slot load per probe); runs whose key is in the slice become items {bucket start, length,
+ * first hit, hits}, compacted into this workgroup's scratch in HBM/L2.  A unit of work is one
+ * (chunk of 256 entries, hit) pair, i.e. four LDS atomics per lane; the running sum of units is
+ * kept for every 64th item.
+ * Phase 2, no barriers: the units are split into 16 equal ranges, one per wave, so the waves
+ * finish together whatever the bucket lengths are.  A wave finds its first item through the
+ * coarse sums, keeps a window of 64 items in registers (one per lane, next window prefetched) and
  * walks its range chunk by chunk with the next chunk's loads in flight. */
-#define VOTE_RND 512
 template <int MODE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t acc[ACC_CELLS + ACC_TRASH_WORDS];
-    __shared__ uint4 s_item[VOTE_RND];
-    __shared__ unsigned long long s_pref[VOTE_RND + 1];
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
     __shared__ unsigned long long s_wave64[VOTE_THREADS / WAVE];
@@ -617,6 +616,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const uint32_t n_runs = a.run_count[ref_local];
     const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
     const uint2 *runs = reinterpret_cast<const uint2 *>(a.runs) + (size_t)ref_local * (a.hit_stride + 1);
+    uint4 *items = reinterpret_cast<uint4 *>(a.items) + (size_t)blockIdx.x * a.hit_stride;
+    unsigned long long *coarse = a.item_sums + (size_t)blockIdx.x * (a.hit_stride / WAVE + 1);
 
     for (int c = tid; c < ACC_CELLS / 4; c += VOTE_THREADS) reinterpret_cast<uint4 *>(acc)[c] = make_uint4(0, 0, 0, 0);
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
@@ -630,140 +631,188 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     sq.n = 0;
 #ifdef VOTE_PROF
     const long long pt0 = clock64();
-    long long pt_busy = 0, pt_items = 0;
+    long long pt_busy = 0;
 #endif
-    __syncthreads();
 
-    for (uint32_t r0 = 0; r0 < n_runs; r0 += VOTE_RND) {
-        /* ---- items of this round and the prefix sum of their units ---- */
-#ifdef VOTE_PROF
-        const long long pt_r = clock64();
-#endif
+    /* ---- phase 1: the items of this (reference point, slice) ---- */
+    unsigned long long total = 0;      /* units so far; the same value in every thread */
+    uint32_t n_items = 0;
+    for (uint32_t r0 = 0; r0 < n_runs; r0 += VOTE_THREADS) {
         unsigned long long units = 0;
-        if (tid < VOTE_RND) {
-            uint4 it = make_uint4(0, 0, 0, 0);
-            const uint32_t u = r0 + (uint32_t)tid;
-            if (u < n_runs) {
-                const uint2 rr = runs[u];
-                const uint32_t R = runs[u + 1].y - rr.y;
-                uint32_t slot = slot_of(rr.x, shift);
-                for (uint32_t probe = 0; probe <= mask; probe++) {
-                    const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
-                    if (sv.x == rr.x) {
-                        /* sv.w bit 31: the bucket holds an entry with the marker */
-                        it = make_uint4(sv.y, sv.z | (sv.w & 0x80000000u), rr.y, R);
-                        units = (unsigned long long)((sv.z + 255u) >> 8) * R;
-                        my_votes += (unsigned long long)sv.z * R;
-#ifdef VOTE_PROF
-                        {
-                            const int cls = sv.z <= 16 ? 0 : sv.z <= 64 ? 1 : sv.z <= 256 ? 2 : sv.z <= 1024 ? 3 : 4;
-                            atomicAdd(&a.counters->prof[4 + cls], units);                       /* units */
-                            atomicAdd(&a.counters->prof[9 + cls], (unsigned long long)sv.z * R); /* votes */
-                            atomicAdd(&a.counters->prof[14], 1ull);                              /* items */
-                            atomicAdd(&a.counters->prof[15], (unsigned long long)((sv.z + 255u) >> 8)); /* chunk loads */
-                        }
-#endif
-                        break;
-                    }
-                    if (sv.x == 0) break;
-                    slot = (slot + 1) & mask;
+        uint4 it = make_uint4(0, 0, 0, 0);
+        const uint32_t u = r0 + (uint32_t)tid;
+        if (u < n_runs) {
+            const uint2 rr = runs[u];
+            const uint32_t R = runs[u + 1].y - rr.y;
+            uint32_t slot = slot_of(rr.x, shift);
+            for (uint32_t probe = 0; probe <= mask; probe++) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
+                if (sv.x == rr.x) {
+                    /* sv.w bit 31: the bucket holds an entry with the marker */
+                    it = make_uint4(sv.y, sv.z | (sv.w & 0x80000000u), rr.y, R);
+                    units = (unsigned long long)((sv.z + 255u) >> 8) * R;
+                    my_votes += (unsigned long long)sv.z * R;
+                    break;
                 }
+                if (sv.x == 0) break;
+                slot = (slot + 1) & mask;
             }
-            s_item[tid] = it;
         }
+        const bool live = units != 0;
+        const unsigned long long lm = __ballot(live);
         unsigned long long incl = units;
         for (int o = 1; o < WAVE; o <<= 1) {
             const unsigned long long up = __shfl_up(incl, o, WAVE);
             if (lane >= o) incl += up;
         }
-        if (lane == WAVE - 1) s_wave64[wid] = incl;
-        __syncthreads();
-        if (tid < VOTE_RND) {
-            unsigned long long before = 0;
-            for (int w = 0; w < wid; w++) before += s_wave64[w];
-            s_pref[tid] = before + incl - units;
-            if (tid == VOTE_RND - 1) s_pref[VOTE_RND] = before + incl;
+        if (lane == WAVE - 1) {
+            s_wave64[wid] = incl;
+            s_wave[wid] = (uint32_t)__popcll(lm);
         }
         __syncthreads();
+        unsigned long long before_u = total, all_u = 0;
+        uint32_t before_n = n_items, all_n = 0;
+        for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
+            const unsigned long long vu = s_wave64[w];
+            const uint32_t vn = s_wave[w];
+            if (w < wid) {
+                before_u += vu;
+                before_n += vn;
+            }
+            all_u += vu;
+            all_n += vn;
+        }
+        if (live) {
+            const uint32_t idx = before_n + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
+            items[idx] = it;
+            if ((idx & (WAVE - 1)) == 0) coarse[idx >> 6] = before_u + incl - units;
+        }
+        total += all_u;
+        n_items += all_n;
+        __syncthreads();            /* s_wave / s_wave64 are rewritten by the next pass */
+    }
+    __threadfence_block();
+    __syncthreads();                /* items and sums visible to every wave; acc zeroed */
 
+    /* ---- phase 2: this wave's share of the units ---- */
+    total = uni_u64(total);
+    n_items = uni_u32(n_items);
+    const uint32_t wu = uni_u32((uint32_t)wid);
+    const unsigned long long lo = (total * wu) >> 4, hi = (total * (wu + 1u)) >> 4;
+    if (hi > lo) {
 #ifdef VOTE_PROF
-        pt_items += clock64() - pt_r;
+        const long long pt_a = clock64();
 #endif
-        /* ---- this wave's share of the round ---- */
-        const unsigned long long total = uni_u64(s_pref[VOTE_RND]);
-        const uint32_t wu = uni_u32((uint32_t)wid);
-        const unsigned long long lo = (total * wu) >> 4, hi = (total * (wu + 1u)) >> 4;
-        if (hi > lo) {
-#ifdef VOTE_PROF
-            const long long pt_a = clock64();
-#endif
-            /* the item that holds unit lo: the last one whose prefix is <= lo */
-            int il = 0, ih = VOTE_RND;
-            while (ih - il > 1) {
-                const int mid = (il + ih) >> 1;
-                if (s_pref[mid] <= lo) il = mid; else ih = mid;
+        /* the block of 64 items that holds unit lo: the last one whose sum is <= lo */
+        const uint32_t n_blocks = (n_items + WAVE - 1) >> 6;
+        uint32_t blk = 0;
+        for (uint32_t base = 0; base < n_blocks; base += WAVE) {
+            const uint32_t bi = base + (uint32_t)lane;
+            const unsigned long long v = bi < n_blocks ? coarse[bi] : ~0ull;
+            const unsigned long long m = __ballot(v <= lo);          /* sums ascend: a prefix of the lanes */
+            if (m) blk = base + (uint32_t)__popcll(m) - 1u;
+            if (m != ~0ull) break;
+        }
+        blk = uni_u32(blk);
+        uint32_t wbase = blk << 6;                                   /* first item of the window */
+        auto load_window = [&](uint32_t first) -> uint4 {
+            const uint32_t k = first + (uint32_t)lane;
+            return k < n_items ? items[k] : make_uint4(0, 0, 0, 0);
+        };
+        uint4 win = load_window(wbase), win_next = load_window(wbase + WAVE);
+        /* the item inside the window: exclusive sums of the window's units */
+        uint32_t kl;
+        uint32_t o;
+        {
+            const unsigned long long wu64 = (unsigned long long)(((win.y & 0x7fffffffu) + 255u) >> 8) * win.w;
+            unsigned long long incl = wu64;
+            for (int s2 = 1; s2 < WAVE; s2 <<= 1) {
+                const unsigned long long up = __shfl_up(incl, s2, WAVE);
+                if (lane >= s2) incl += up;
             }
-            /* generator state, wave-uniform */
-            int item = (int)uni_u32((uint32_t)il);
-            unsigned long long remaining = hi - lo;
-            uint32_t g_st, g_ln, g_h0, g_R, g_C, g_c, g_i0;
-            bool g_bf;
-            auto open_item = [&](int k) {
-                const uint4 it = s_item[k];
-                g_st = uni_u32(it.x);
-                const uint32_t lf = uni_u32(it.y);
-                g_ln = lf & 0x7fffffffu;
-                g_bf = (lf >> 31) != 0;
-                g_h0 = uni_u32(it.z);
-                g_R = uni_u32(it.w);
-                g_C = (g_ln + 255u) >> 8;
-            };
-            open_item(item);
-            {
-                const uint32_t o = uni_u32((uint32_t)(lo - s_pref[item]));
-                g_c = o / g_R;
-                g_i0 = o - g_c * g_R;
-            }
-            auto next_step = [&]() -> VoteStep {
-                VoteStep d;
-                d.valid = remaining != 0;
-                d.st = g_st; d.off = g_c << 8; d.ln = g_ln; d.h0 = g_h0; d.R = g_R; d.bforced = g_bf;
+            const unsigned long long pref = coarse[blk] + incl - wu64;
+            const unsigned long long m = __ballot(wu64 != 0 && pref <= lo);
+            kl = (uint32_t)__popcll(m) - 1u;                         /* m != 0: the block's first item qualifies */
+            const unsigned long long d = lo - pref;
+            o = readlane_u((uint32_t)d, (int)kl);
+        }
+        /* generator state, wave-uniform.  The budget is handed out in 32-bit portions so that the
+         * per-step arithmetic stays 32-bit (a portion only ends early in absurdly large cases). */
+        unsigned long long budget = hi - lo;
+        uint32_t remaining = 0;
+        uint32_t g_st = 0, g_ln = 0, g_h0 = 0, g_R = 1, g_C = 0, g_c, g_i0;
+        bool g_bf = false;
+        auto open_item = [&]() {
+            g_st = readlane_u(win.x, (int)kl);
+            const uint32_t lf = readlane_u(win.y, (int)kl);
+            g_ln = lf & 0x7fffffffu;
+            g_bf = (lf >> 31) != 0;
+            g_h0 = readlane_u(win.z, (int)kl);
+            g_R = readlane_u(win.w, (int)kl);
+            g_C = (g_ln + 255u) >> 8;
+        };
+        open_item();
+        g_c = o / g_R;
+        g_i0 = o - g_c * g_R;
+        auto next_step = [&]() -> VoteStep {
+            VoteStep d;
+            d.valid = remaining != 0;
+            if (d.valid) {
+                if (g_c == g_C) {                  /* the previous step finished its item */
+                    kl++;
+                    if (kl == WAVE) {              /* next window; the one after it goes in flight */
+                        win = win_next;
+                        wbase += WAVE;
+                        kl = 0;
+                        win_next = load_window(wbase + WAVE);
+                    }
+                    open_item();
+                    g_c = 0;
+                }
+                const uint32_t off = g_c << 8;
+                d.chunk = a.ent.e4 + g_st + off;
+                d.hit0 = hits + g_h0;
+                d.left = g_ln - off;
+                d.entry0 = g_st + off;
+                d.hbase = g_h0;
+                d.R = g_R;
+                d.bforced = g_bf;
                 d.i0 = (int)g_i0;
                 uint32_t nh = g_R - g_i0;
-                if ((unsigned long long)nh > remaining) nh = (uint32_t)remaining;
+                nh = nh < remaining ? nh : remaining;
                 d.i1 = (int)(g_i0 + nh);
-                if (d.valid) {
-                    remaining -= nh;
-                    g_i0 = 0;
-                    g_c++;
-                    if (g_c == g_C && remaining != 0) {
-                        do {                       /* items without units: the key is not in this slice */
-                            item++;
-                            if (item >= VOTE_RND) break;     /* cannot happen: the prefix sums cover `remaining` */
-                            open_item(item);
-                        } while (g_C == 0 || g_R == 0);
-                        if (item >= VOTE_RND) remaining = 0;
-                        g_c = 0;
-                    }
-                }
-                return d;
-            };
-            VoteStep d0 = next_step();
-            VR c0;
-            c0.load(a, hits, d0, lane);
-            while (d0.valid) {
-                const VoteStep d1 = next_step();
-                VR c1 = c0;
-                if (d1.valid) c1.load(a, hits, d1, lane);
-                c0.vote(a, hits, acc, s_tbl, sq, d0, lane);
-                c0 = c1;
-                d0 = d1;
+                remaining -= nh;
+                g_i0 = 0;
+                g_c++;
             }
-#ifdef VOTE_PROF
-            pt_busy += clock64() - pt_a;
-#endif
+            return d;
+        };
+        while (budget) {
+            remaining = budget > 0x40000000ull ? 0x40000000u : (uint32_t)budget;
+            budget -= remaining;
+            /* the loads of the next VOTE_PIPE steps are in flight while a step is voted: the kernel is
+             * bound by the latency of the entry stream (HBM / Infinity Cache), not by issue */
+            VR c[VOTE_PIPE + 1];
+            VoteStep d[VOTE_PIPE + 1];
+#pragma unroll
+            for (int k = 0; k < VOTE_PIPE; k++) {
+                d[k] = next_step();
+                if (d[k].valid) c[k].load(d[k], lane);
+            }
+            while (d[0].valid) {
+                d[VOTE_PIPE] = next_step();
+                if (d[VOTE_PIPE].valid) c[VOTE_PIPE].load(d[VOTE_PIPE], lane);
+                c[0].vote(a, hits, acc, s_tbl, sq, d[0], lane);
+#pragma unroll
+                for (int k = 0; k < VOTE_PIPE; k++) {
+                    c[k] = c[k + 1];
+                    d[k] = d[k + 1];
+                }
+            }
         }
-        __syncthreads();            /* the next round rewrites the items */
+#ifdef VOTE_PROF
+        pt_busy += clock64() - pt_a;
+#endif
     }
     if (MODE == 0) sq.flush(a, hits, acc, s_tbl, lane);
 #ifdef VOTE_PROF
@@ -774,7 +823,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const long long pt2 = clock64();
     if (lane == 0) {
         atomicAdd(&a.counters->prof[0], (unsigned long long)(pt1 - pt0));
-        atomicAdd(&a.counters->prof[1], (unsigned long long)pt_items);
+        atomicAdd(&a.counters->prof[1], (unsigned long long)(pt2 - pt0));
         atomicAdd(&a.counters->prof[3], (unsigned long long)pt_busy);
     }
 #endif
