@@ -182,8 +182,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_vote", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(args, M, S, df),
-                         "traffic_note": "HBM-side bytes per vote-kernel launch (rocprofv3 PMC, profiles/); below the "
-                                         "algorithmic bytes because a model-pair entry is packed into 4 bytes",
+                         "traffic_note": "HBM-side bytes per vote-kernel launch (rocprofv3 PMC, profiles/). Far below the "
+                                         "algorithmic bytes, and frac above 1, because the SURVEY 8d model charges 8 B to "
+                                         "every vote while the kernel packs an entry into 4 B and streams a bucket once "
+                                         "for all hits of a reference point that share it; the kernel is bound by "
+                                         "LDS-atomic and vector issue, not by HBM (DESIGN.md 4)",
                          "alg_bytes_per_launch": per_launch_bytes, "launch_ms": per_launch_ms,
                          "launches_per_step": launches / args.steps,
                          "key_kernel_ms_per_step": ms_key_kernel / args.steps,
