@@ -453,7 +453,7 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
 
 /* Scratch for the hit lists of one batch of reference points: one pool per device, shared by all
  * models (it is only live inside an align call; like the reference, calls on one device are not
- * re-entrant).  Up to OSLAM_SCRATCH_GIB (default 16) GiB, at least one reference point's worth. */
+ * re-entrant).  Up to OSLAM_SCRATCH_GIB GiB (default: a quarter of the free device memory, at least 16), at least one reference point's worth. */
 #define MAX_DEVICES 64
 typedef struct {
     oslamk_hit *hits;
@@ -477,12 +477,24 @@ static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratc
     size_t batch;
     if (m->dev < 0 || m->dev >= MAX_DEVICES) return fail(OSLAM_E_LIMIT, "device ordinal too large");
     p = &g_pool[m->dev];
-    if (env && atoi(env) > 0) cap = (size_t)atoi(env) << 30;
+    if (env && atoi(env) > 0) {
+        cap = (size_t)atoi(env) << 30;
+    } else {
+        /* default: a quarter of what is free now (72 GB of an idle MI355X), at least 16 GiB */
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (fr + p->hits_bytes) / 4 > cap) cap = (fr + p->hits_bytes) / 4;
+    }
     if (want > cap) want = cap;
     if (want < per_ref) want = per_ref;
     if (p->hits_bytes < want) {
         if (p->hits) { (void)hipFree(p->hits); p->hits = NULL; p->hits_bytes = 0; }
-        HIPCHK(hipMalloc((void **)&p->hits, want));
+        /* a refused allocation is retried at half the size, down to one reference point's worth */
+        while (hipMalloc((void **)&p->hits, want) != hipSuccess) {
+            (void)hipGetLastError();
+            p->hits = NULL;
+            if (want <= per_ref) return fail(OSLAM_E_NOMEM, "no device memory for the hit lists of one reference point");
+            want = want / 2 > per_ref ? want / 2 : per_ref;
+        }
         p->hits_bytes = want;
     }
     batch = p->hits_bytes / per_ref;

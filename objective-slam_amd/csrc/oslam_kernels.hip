@@ -504,8 +504,9 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
  * vote kernel works from: runs[u] = {key, index of the run's first hit}; a run also ends at every
  * multiple of 64 hits, so a run piece is at most one hit per lane; runs[n_runs] = {0, n_hits}.
  * One workgroup per reference point: bitonic sort of (key << 32 | index) in LDS, then the records
- * are gathered into the second list.  Lists longer than SORT_MAX stay in arrival order with one
- * run per hit (still correct, the buckets are just streamed once per hit). */
+ * are gathered into the second list.  A list longer than SORT_MAX is sorted in segments of
+ * SORT_MAX hits (a key then has one run per segment it occurs in: its bucket is streamed once
+ * per segment instead of once, everything else is unchanged). */
 #define SORT_MAX 16384
 #define SORT_THREADS 1024
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
@@ -513,70 +514,66 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
     __shared__ unsigned long long buf[SORT_MAX];
     __shared__ uint32_t s_part[SORT_THREADS / WAVE];
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-    const uint32_t n = a.hit_count[ref_local];
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
-    uint4 *dst = reinterpret_cast<uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
+    const uint32_t n_all = a.hit_count[ref_local];
+    const uint4 *src_all = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
+    uint4 *dst_all = reinterpret_cast<uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
     uint2 *runs = reinterpret_cast<uint2 *>(a.runs) + (size_t)ref_local * (a.hit_stride + 1);
-    if (n > SORT_MAX) {
-        for (uint32_t i = tid; i < n; i += SORT_THREADS) {
-            const uint4 r = src[i];
-            dst[i] = r;
-            runs[i] = make_uint2(r.x, i);
-        }
-        if (tid == 0) {
-            runs[n] = make_uint2(0u, n);
-            a.run_count[ref_local] = n;
-        }
-        return;
-    }
-    uint32_t P = 64;
-    while (P < n) P <<= 1;
-    for (uint32_t i = tid; i < P; i += SORT_THREADS)
-        buf[i] = i < n ? ((unsigned long long)src[i].x << 32) | i : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < P / 2; t += SORT_THREADS) {
-                /* t-th compare-exchange of this pass: partner indices differ in bit j */
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                const unsigned long long x = buf[lo], y = buf[hi];
-                const bool up = (lo & k) == 0;
-                if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+    uint32_t n_runs = 0;                /* the same value in every thread */
+    for (uint32_t seg = 0; seg < n_all; seg += SORT_MAX) {
+        const uint32_t n = n_all - seg < SORT_MAX ? n_all - seg : SORT_MAX;
+        const uint4 *src = src_all + seg;
+        uint4 *dst = dst_all + seg;
+        uint32_t P = 64;
+        while (P < n) P <<= 1;
+        for (uint32_t i = tid; i < P; i += SORT_THREADS)
+            buf[i] = i < n ? ((unsigned long long)src[i].x << 32) | i : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < P / 2; t += SORT_THREADS) {
+                    /* t-th compare-exchange of this pass: partner indices differ in bit j */
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const unsigned long long x = buf[lo], y = buf[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
-    }
-    for (uint32_t i = tid; i < n; i += SORT_THREADS) dst[i] = src[(uint32_t)buf[i]];
+        for (uint32_t i = tid; i < n; i += SORT_THREADS) dst[i] = src[(uint32_t)buf[i]];
 
-    /* run heads: thread t owns sorted positions [t*per, (t+1)*per) */
-    const uint32_t per = SORT_MAX / SORT_THREADS, i0 = (uint32_t)tid * per;
-    uint32_t heads = 0, cnt = 0;
-    for (uint32_t k = 0; k < per; k++) {
-        const uint32_t i = i0 + k;
-        if (i < n) {
-            const bool head = (i & (WAVE - 1)) == 0 || (uint32_t)(buf[i] >> 32) != (uint32_t)(buf[i - 1] >> 32);
-            heads |= (uint32_t)head << k;
-            cnt += head;
+        /* run heads: thread t owns sorted positions [t*per, (t+1)*per) of the segment */
+        const uint32_t per = SORT_MAX / SORT_THREADS, i0 = (uint32_t)tid * per;
+        uint32_t heads = 0, cnt = 0;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t i = i0 + k;
+            if (i < n) {
+                const bool head = (i & (WAVE - 1)) == 0 || (uint32_t)(buf[i] >> 32) != (uint32_t)(buf[i - 1] >> 32);
+                heads |= (uint32_t)head << k;
+                cnt += head;
+            }
         }
+        uint32_t incl = cnt;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == WAVE - 1) s_part[wid] = incl;
+        __syncthreads();
+        uint32_t pos = n_runs + incl - cnt, total = 0;
+        for (int w = 0; w < SORT_THREADS / WAVE; w++) {
+            const uint32_t v = s_part[w];
+            if (w < wid) pos += v;
+            total += v;
+        }
+        for (uint32_t k = 0; k < per; k++)
+            if ((heads >> k) & 1u) runs[pos++] = make_uint2((uint32_t)(buf[i0 + k] >> 32), seg + i0 + k);
+        n_runs += total;
+        __syncthreads();                /* buf and s_part are reused by the next segment */
     }
-    uint32_t incl = cnt;
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += up;
-    }
-    if (lane == WAVE - 1) s_part[wid] = incl;
-    __syncthreads();
-    uint32_t pos = incl - cnt, total = 0;
-    for (int w = 0; w < SORT_THREADS / WAVE; w++) {
-        const uint32_t v = s_part[w];
-        if (w < wid) pos += v;
-        total += v;
-    }
-    for (uint32_t k = 0; k < per; k++)
-        if ((heads >> k) & 1u) runs[pos++] = make_uint2((uint32_t)(buf[i0 + k] >> 32), i0 + k);
     if (tid == 0) {
-        runs[total] = make_uint2(0u, n);
-        a.run_count[ref_local] = total;
+        runs[n_runs] = make_uint2(0u, n_all);
+        a.run_count[ref_local] = n_runs;
     }
 }
 

@@ -72,6 +72,23 @@ def test_accumulator_exact(ppf, oracle, built_lib, case_small):
         assert np.array_equal(got, want), r
 
 
+def test_accumulator_long_hit_lists(ppf, oracle, built_lib, synth):
+    # scene = a dense sampling of the model's own surface, coarse d_dist: a large share of the scene
+    # pairs hit, > 16384 hits per reference point, so the hit list is sorted in segments and a key has
+    # runs in several segments; > 64 equal keys in a row also exercises the run split at 64 hits
+    mp, mn = synth.make_model(0, 150)
+    d = synth.d_dist_for(mp, 0.25)
+    sp, sn = synth.make_model(0, 60000)
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=20000)
+    mo = ppf.Model(mp, mn, d_dist=d)
+    mo.ppf_lookup(sc, allow_no_votes=True)
+    assert mo.stats["num_hits"] > 3 * 16384 * 1.2      # 3 reference points, each past one segment
+    for r in (0, 40000):
+        got = mo.vote_accumulator(sc, r)
+        want = oracle.accumulator_for_ref(mp, mn, sp, sn, r, d)
+        assert np.array_equal(got, want), r
+
+
 def _align_and_compare(ppf, oracle, c, df=1, **flags):
     par = ppf.default_params()
     sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=df, params=par)
