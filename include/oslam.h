@@ -100,6 +100,19 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
                        float d_dist, const oslam_params *params, oslam_model **out);
 void oslam_model_destroy(oslam_model *m);
 
+/* Persistent model database (the reference rebuilds every model for every scene, src/cuda/ppf.cu:57-70;
+ * its own comment at :64-66 asks for this): oslam_model_save writes the built table -- cloud, slice
+ * tables, union table, reachable-distance bitset, pair entries, point weights -- to one file;
+ * oslam_model_load maps it back into HBM without recomputing a pair.  The file is tied to the
+ * table layout version and to the vote mode it was built with (a fast-mode table has no exact
+ * entries); a mismatch or a damaged file is OSLAM_E_INVALID.  params (may be NULL) supplies the
+ * run-time flags of the loaded model (device, clustering flags, threshold); the table fields of
+ * the file win. */
+int oslam_model_save(const oslam_model *m, const char *path);
+int oslam_model_load(const char *path, const oslam_params *params, oslam_model **out);
+/* size of a built model: points, d_dist and the bytes its table holds in HBM (any pointer may be NULL) */
+int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint64_t *table_bytes);
+
 /* Model::SetModelPointVoteWeights (include/model.h:22); weights[n], default all 1. */
 int oslam_model_set_point_weights(oslam_model *m, const float *weights, size_t n);
 
@@ -137,6 +150,22 @@ int oslam_ht_dist(const float A[16], const float B[16], float out[2]);
  * number of voxels (OSLAM_E_LIMIT if it exceeds cap or the voxel count overflows int32). */
 int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride_bytes, float leaf,
                      int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out);
+
+/* Depth image -> scene cloud with normals: the front end of a streaming configuration (a range camera
+ * feeding the PPF path; the reference takes finished clouds from KinFu, README.md:5-8, and has no code
+ * for this step -- the specification is oracle/oracle_depth.c).  Pinhole camera, z along the optical
+ * axis: z = raw * depth_scale, valid in [z_min, z_max]; normals from the four axis neighbours (all
+ * valid and within max_jump of z), unit length, facing the camera.  Pixels without a normal are
+ * dropped; the rest come out in row-major pixel order.  depth: host image, uint16 (depth_is_u16 != 0)
+ * or float, width x height.  xyz_out / nrm_out: packed float[cap][3]. */
+typedef struct oslam_camera {
+    float fx, fy, cx, cy;          /* pixels */
+    float depth_scale;             /* raw unit -> metres (0.001 for millimetre images) */
+    float z_min, z_max;            /* metres */
+    float max_jump;                /* metres: no normal across a larger depth step */
+} oslam_camera;
+int oslam_depth_to_cloud(const void *depth, int depth_is_u16, int width, int height, const oslam_camera *cam,
+                         int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out);
 
 /* PLY clouds with normals (host only): pcl::io::loadPLYFile<pcl::PointNormal>
  * (src/alignment.cpp:212,241) / pcl::PLYWriter (pcl/voxel_grid/voxel_grid.cpp:27-29).

@@ -245,6 +245,46 @@ done:
 }
 
 /* ------------------------------------------------------------------------ */
+int oslam_depth_to_cloud(const void *depth, int depth_is_u16, int width, int height, const oslam_camera *cam,
+                         int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out)
+{
+    int rc = OSLAM_OK, k, devsel;
+    void *d_img = NULL;
+    float *d_out = NULL, *h_out = NULL;
+    uint32_t np = 0;
+    size_t i, n_pix, px_bytes;
+    if (!depth || !cam || !xyz_out || !nrm_out || !n_out || width < 3 || height < 3 || width > 16384 || height > 16384 ||
+        !(cam->fx > 0.0f) || !(cam->fy > 0.0f) || !(cam->depth_scale > 0.0f) || !(cam->z_max >= cam->z_min) ||
+        !(cam->z_min > 0.0f) || !(cam->max_jump >= 0.0f))
+        return fail(OSLAM_E_INVALID, "bad depth image arguments");
+    *n_out = 0;
+    n_pix = (size_t)width * (size_t)height;
+    px_bytes = depth_is_u16 ? 2 : 4;
+    rc = pick_device(dev, &devsel);
+    if (rc != OSLAM_OK) return rc;
+    HIPCHK(hipMalloc(&d_img, n_pix * px_bytes));
+    HIPCHK(hipMalloc((void **)&d_out, sizeof(float) * 6 * n_pix));
+    HIPCHK(hipMemcpyAsync(d_img, depth, n_pix * px_bytes, hipMemcpyHostToDevice, (hipStream_t)g_stream));
+    k = oslamk_depth_to_cloud(d_img, depth_is_u16 != 0, width, height, cam->fx, cam->fy, cam->cx, cam->cy, cam->depth_scale,
+                              cam->z_min, cam->z_max, cam->max_jump, d_out, &np, g_stream);
+    if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
+    if (np > cap) { rc = fail(OSLAM_E_LIMIT, "output capacity too small"); goto done; }
+    h_out = (float *)malloc(sizeof(float) * 6 * (np ? np : 1));
+    if (!h_out) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    if (np) HIPCHK(hipMemcpy(h_out, d_out, sizeof(float) * 6 * np, hipMemcpyDeviceToHost));
+    for (i = 0; i < np; i++) {
+        memcpy(xyz_out + 3 * i, h_out + 6 * i, 3 * sizeof(float));
+        memcpy(nrm_out + 3 * i, h_out + 6 * i + 3, 3 * sizeof(float));
+    }
+    *n_out = np;
+done:
+    free(h_out);
+    if (d_img) (void)hipFree(d_img);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
 void oslam_model_destroy(oslam_model *m)
 {
     if (!m) return;
@@ -369,6 +409,211 @@ done:
     if (d_small) (void)hipFree(d_small);
     if (rc != OSLAM_OK) { oslam_model_destroy(m); return rc; }
     *out = m;
+    return OSLAM_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * persistent model database: one file per built model
+ * ---------------------------------------------------------------------- */
+#define OSLAM_DB_MAGIC 0x4c444d4f534c4f00ull     /* "\0OLSOMDL" */
+#define OSLAM_DB_VERSION 3u                      /* table layout: 16-B slots, e4 = m_r<<22 | theta (2^-22 turn) */
+typedef struct db_header {
+    uint64_t magic;
+    uint32_t version, vote_mode;
+    uint32_t n_points, n_slices, cap, shift, ucap, ushift, n_entries, has_uv;
+    uint64_t num_model_keys;
+    float d_dist, inv_d_dist;
+    uint64_t checksum;                           /* FNV-1a 64 over every payload byte, in file order */
+} db_header;
+
+static uint64_t fnv64(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i;
+    for (i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+/* device array <-> file through a bounded staging buffer */
+static int db_write_dev(FILE *f, const void *dev, size_t bytes, uint64_t *sum)
+{
+    int rc = OSLAM_OK;
+    const size_t chunk = (size_t)64 << 20;
+    char *h = (char *)malloc(bytes < chunk ? (bytes ? bytes : 1) : chunk);
+    size_t off;
+    if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    for (off = 0; off < bytes; off += chunk) {
+        const size_t n = bytes - off < chunk ? bytes - off : chunk;
+        HIPCHK(hipMemcpy(h, (const char *)dev + off, n, hipMemcpyDeviceToHost));
+        *sum = fnv64(*sum, h, n);
+        if (fwrite(h, 1, n, f) != n) { rc = fail(OSLAM_E_INVALID, "short write"); goto done; }
+    }
+done:
+    free(h);
+    return rc;
+}
+
+static int db_read_dev(FILE *f, void *dev, size_t bytes, uint64_t *sum)
+{
+    int rc = OSLAM_OK;
+    const size_t chunk = (size_t)64 << 20;
+    char *h = (char *)malloc(bytes < chunk ? (bytes ? bytes : 1) : chunk);
+    size_t off;
+    if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    for (off = 0; off < bytes; off += chunk) {
+        const size_t n = bytes - off < chunk ? bytes - off : chunk;
+        if (fread(h, 1, n, f) != n) { rc = fail(OSLAM_E_INVALID, "model file is truncated"); goto done; }
+        *sum = fnv64(*sum, h, n);
+        HIPCHK(hipMemcpy((char *)dev + off, h, n, hipMemcpyHostToDevice));
+    }
+done:
+    free(h);
+    return rc;
+}
+
+int oslam_model_save(const oslam_model *m, const char *path)
+{
+    int rc = OSLAM_OK;
+    FILE *f = NULL;
+    db_header hd;
+    uint64_t sum = 0xcbf29ce484222325ull;
+    const size_t n = m ? (size_t)m->c.n : 0;
+    if (!m || !path) return fail(OSLAM_E_INVALID, "NULL argument");
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    memset(&hd, 0, sizeof hd);
+    hd.magic = OSLAM_DB_MAGIC;
+    hd.version = OSLAM_DB_VERSION;
+    hd.vote_mode = (uint32_t)m->params.vote_mode;
+    hd.n_points = (uint32_t)n;
+    hd.n_slices = (uint32_t)m->table.n_slices;
+    hd.cap = m->table.cap;
+    hd.shift = m->table.shift;
+    hd.ucap = m->table.ucap;
+    hd.ushift = m->table.ushift;
+    hd.n_entries = m->n_entries;
+    hd.has_uv = m->ent.uv ? 1u : 0u;
+    hd.num_model_keys = m->num_model_keys;
+    hd.d_dist = m->d_dist;
+    hd.inv_d_dist = m->inv_d_dist;
+    f = fopen(path, "wb");
+    if (!f) return fail(OSLAM_E_INVALID, "cannot open the model file for writing");
+    if (fwrite(&hd, sizeof hd, 1, f) != 1) { rc = fail(OSLAM_E_INVALID, "short write"); goto done; }
+    /* payload: host cloud, weights, then the device arrays */
+    sum = fnv64(sum, m->c.h_xyz, 12 * n);
+    sum = fnv64(sum, m->c.h_nrm, 12 * n);
+    sum = fnv64(sum, m->weights, 4 * n);
+    if (fwrite(m->c.h_xyz, 12, n, f) != n || fwrite(m->c.h_nrm, 12, n, f) != n || fwrite(m->weights, 4, n, f) != n) {
+        rc = fail(OSLAM_E_INVALID, "short write");
+        goto done;
+    }
+    rc = db_write_dev(f, m->table.slots, sizeof(oslamk_slot) * (size_t)hd.cap * hd.n_slices, &sum);
+    if (rc == OSLAM_OK) rc = db_write_dev(f, m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap, &sum);
+    if (rc == OSLAM_OK) rc = db_write_dev(f, m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), &sum);
+    if (rc == OSLAM_OK) rc = db_write_dev(f, m->ent.e4, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK) rc = db_write_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.uv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
+    if (rc != OSLAM_OK) goto done;
+    hd.checksum = sum;
+    if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&hd, sizeof hd, 1, f) != 1) rc = fail(OSLAM_E_INVALID, "short write");
+done:
+    if (f && fclose(f) != 0 && rc == OSLAM_OK) rc = fail(OSLAM_E_INVALID, "short write");
+    return rc;
+}
+
+int oslam_model_load(const char *path, const oslam_params *params, oslam_model **out)
+{
+    int rc = OSLAM_OK;
+    FILE *f = NULL;
+    db_header hd;
+    oslam_model *m = NULL;
+    float *xyz = NULL, *nrm = NULL;
+    uint64_t sum = 0xcbf29ce484222325ull;
+    size_t n, n_pairs;
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (!path) return fail(OSLAM_E_INVALID, "path is NULL");
+    f = fopen(path, "rb");
+    if (!f) return fail(OSLAM_E_INVALID, "cannot open the model file");
+    if (fread(&hd, sizeof hd, 1, f) != 1 || hd.magic != OSLAM_DB_MAGIC) { rc = fail(OSLAM_E_INVALID, "not a model file"); goto done; }
+    if (hd.version != OSLAM_DB_VERSION) { rc = fail(OSLAM_E_INVALID, "model file has another table layout version"); goto done; }
+    n = hd.n_points;
+    if (n < 2 || n > 46340 || hd.n_slices != (n + OSLAMK_SLICE - 1) / OSLAMK_SLICE || hd.n_slices > 64 ||
+        hd.cap == 0 || (hd.cap & (hd.cap - 1)) || hd.ucap == 0 || (hd.ucap & (hd.ucap - 1)) || hd.cap > (1u << 26) ||
+        !(hd.d_dist > 0.0f)) {
+        rc = fail(OSLAM_E_INVALID, "model file header is inconsistent");
+        goto done;
+    }
+    m = (oslam_model *)calloc(1, sizeof *m);
+    if (!m) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    if (params) m->params = *params; else oslam_params_default(&m->params);
+    if (m->params.max_cells == 0) m->params.max_cells = 1u << 22;
+    if (params && (uint32_t)params->vote_mode != hd.vote_mode && !(hd.has_uv && params->vote_mode == OSLAM_VOTE_FAST)) {
+        rc = fail(OSLAM_E_INVALID, "model file was built in fast vote mode: it has no exact entries");
+        goto done;
+    }
+    if (!params) m->params.vote_mode = (int)hd.vote_mode;
+    rc = pick_device(m->params.dev, &m->dev);
+    if (rc != OSLAM_OK) goto done;
+    xyz = (float *)malloc(12 * n);
+    nrm = (float *)malloc(12 * n);
+    m->weights = (float *)malloc(4 * n);
+    if (!xyz || !nrm || !m->weights) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    if (fread(xyz, 12, n, f) != n || fread(nrm, 12, n, f) != n || fread(m->weights, 4, n, f) != n) {
+        rc = fail(OSLAM_E_INVALID, "model file is truncated");
+        goto done;
+    }
+    sum = fnv64(sum, xyz, 12 * n);
+    sum = fnv64(sum, nrm, 12 * n);
+    sum = fnv64(sum, m->weights, 4 * n);
+    rc = cloud_upload(&m->c, xyz, nrm, n, 12);
+    if (rc != OSLAM_OK) goto done;
+    m->d_dist = hd.d_dist;
+    m->inv_d_dist = hd.inv_d_dist;
+    m->table.cap = hd.cap;
+    m->table.shift = hd.shift;
+    m->table.n_slices = (int)hd.n_slices;
+    m->table.ucap = hd.ucap;
+    m->table.ushift = hd.ushift;
+    m->n_entries = hd.n_entries;
+    m->num_model_keys = hd.num_model_keys;
+    n_pairs = hd.n_entries ? hd.n_entries : 1;
+    HIPCHK(hipMalloc((void **)&m->table.slots, sizeof(oslamk_slot) * (size_t)hd.cap * hd.n_slices));
+    HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap));
+    HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
+    HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * n_pairs));
+    HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
+    if (hd.has_uv) HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
+    rc = db_read_dev(f, m->table.slots, sizeof(oslamk_slot) * (size_t)hd.cap * hd.n_slices, &sum);
+    if (rc == OSLAM_OK) rc = db_read_dev(f, m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap, &sum);
+    if (rc == OSLAM_OK) rc = db_read_dev(f, m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), &sum);
+    if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.e4, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.uv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
+    if (rc != OSLAM_OK) goto done;
+    if (sum != hd.checksum) { rc = fail(OSLAM_E_INVALID, "model file checksum mismatch"); goto done; }
+    m->out_cap = m->params.max_cells;
+    HIPCHK(hipMalloc((void **)&m->d_counters, sizeof(oslamk_counters)));
+    HIPCHK(hipMalloc((void **)&m->d_out, sizeof(oslamk_cell) * (size_t)m->out_cap));
+    m->h_out = (oslam_cell *)malloc(sizeof(oslam_cell) * (size_t)m->out_cap);
+    if (!m->h_out) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+done:
+    if (f) fclose(f);
+    free(xyz);
+    free(nrm);
+    if (rc != OSLAM_OK) { oslam_model_destroy(m); return rc; }
+    *out = m;
+    return OSLAM_OK;
+}
+
+int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint64_t *table_bytes)
+{
+    if (!m) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (n_points) *n_points = (size_t)m->c.n;
+    if (d_dist) *d_dist = m->d_dist;
+    if (table_bytes)
+        *table_bytes = sizeof(oslamk_slot) * (uint64_t)m->table.cap * (uint64_t)m->table.n_slices +
+                       sizeof(uint32_t) * (uint64_t)m->table.ucap + sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32) +
+                       (uint64_t)m->n_entries * (4 + 2 + (m->ent.uv ? 8 : 0)) + 24ull * (uint64_t)m->c.n;
     return OSLAM_OK;
 }
 

@@ -149,6 +149,12 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream);
  * hipError_t, or -1 when the voxel count overflows int32 */
 int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32_t *n_out, void *stream);
 
+/* depth image -> points + normals (oslam_depth.hip): d_img = device image (uint16 or float, w x h),
+ * d_out6 = device [w*h][6]; the pixels that get a normal, in row-major order; returns a hipError_t */
+int oslamk_depth_to_cloud(const void *d_img, int is_u16, int w, int h, float fx, float fy, float cx, float cy,
+                          float scale, float z_min, float z_max, float max_jump, float *d_out6, uint32_t *n_out,
+                          void *stream);
+
 /* clustering scores of n poses (device arrays).  shash[j] = cell hash of the j-th pose in
  * (hash, pose index) order; sq/st/sw = quaternions [n][4], translations [n][3], weighted votes [n]
  * in that order; trans/quat/cell in pose order.  The translation-averaging variant stays on the host. */

@@ -57,6 +57,9 @@ _SIGNATURES = {
     "oslam_model_create": (_i, [_vp, _vp, _sz, _sz, _f, C.POINTER(Params), C.POINTER(_vp)]),
     "oslam_model_destroy": (None, [_vp]),
     "oslam_model_set_point_weights": (_i, [_vp, _vp, _sz]),
+    "oslam_model_save": (_i, [_vp, C.c_char_p]),
+    "oslam_model_load": (_i, [C.c_char_p, C.POINTER(Params), C.POINTER(_vp)]),
+    "oslam_model_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_f), C.POINTER(C.c_uint64)]),
     "oslam_scene_create": (_i, [_vp, _vp, _sz, _sz, _f, _u, C.POINTER(Params), C.POINTER(_vp)]),
     "oslam_scene_destroy": (None, [_vp]),
     "oslam_align": (_i, [_vp, _vp, _vp, C.POINTER(Stats)]),
@@ -65,6 +68,7 @@ _SIGNATURES = {
     "oslam_ply_read": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "oslam_ply_write": (_i, [C.c_char_p, _vp, _vp, _sz, _i]),
     "oslam_free": (None, [_vp]),
+    "oslam_depth_to_cloud": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_voxel_grid": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_build_T_g": (None, [_vp, _vp, _vp]),
     "oslam_sort_cells": (None, [_vp, _sz]),
@@ -202,6 +206,31 @@ class Model:
 
     def numPoints(self):
         return self.n
+
+    # -- persistent model database (ppf.cu:64-66 asks for it; the reference rebuilds per pair) --
+    def save(self, path):
+        """Write the built table to `path` (oslam_model_save)."""
+        _check(lib().oslam_model_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path, params=None):
+        """A model whose table comes from a file written by save(): nothing is recomputed."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(0)
+        self.params = params if params is not None else default_params()
+        self.best_T = None
+        self.stats = None
+        _check(lib().oslam_model_load(os.fsencode(path), C.byref(self.params) if params is not None else None,
+                                      C.byref(self._h)))
+        n, d = C.c_size_t(0), C.c_float(0)
+        _check(lib().oslam_model_info(self._h, C.byref(n), C.byref(d), None))
+        self.n, self.d_dist = n.value, d.value
+        return self
+
+    def table_bytes(self):
+        b = C.c_uint64(0)
+        _check(lib().oslam_model_info(self._h, None, None, C.byref(b)))
+        return int(b.value)
 
     def SetModelPointVoteWeights(self, weights):
         w = np.ascontiguousarray(weights, np.float32)
@@ -341,6 +370,26 @@ def voxel_grid(points, normals=None, leaf=None, dev=0):
     po, no = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
     k = C.c_size_t(0)
     _check(lib().oslam_voxel_grid(xyz, nrm, n, stride, float(leaf), int(dev), _p(po), _p(no), n, C.byref(k)))
+    return po[: k.value].copy(), no[: k.value].copy()
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("depth_scale", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("max_jump", C.c_float)]
+
+
+def depth_to_cloud(depth, fx, fy, cx, cy, depth_scale=0.001, z_min=0.1, z_max=10.0, max_jump=0.05, dev=0):
+    """Depth image (uint16 or float32, [h,w]) -> (points, normals) in camera coordinates
+    (oslam_depth_to_cloud; specification: oracle/oracle_depth.c)."""
+    d = np.ascontiguousarray(depth)
+    if d.dtype not in (np.uint16, np.float32) or d.ndim != 2:
+        raise ValueError("depth must be a 2-D uint16 or float32 image")
+    cam = Camera(fx, fy, cx, cy, depth_scale, z_min, z_max, max_jump)
+    n = d.size
+    po, no = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    k = C.c_size_t(0)
+    _check(lib().oslam_depth_to_cloud(_p(d), int(d.dtype == np.uint16), d.shape[1], d.shape[0], C.byref(cam), int(dev),
+                                      _p(po), _p(no), n, C.byref(k)))
     return po[: k.value].copy(), no[: k.value].copy()
 
 

@@ -171,3 +171,27 @@ def transform_cloud(points, normals, T):
     R, t = T[:3, :3], T[:3, 3]
     return (np.ascontiguousarray(points.astype(np.float64) @ R.T + t, np.float32),
             np.ascontiguousarray(normals.astype(np.float64) @ R.T, np.float32))
+
+
+def render_depth(points, width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5, depth_scale=0.001,
+                 background_z=None, splat=1):
+    """Z-buffer rendering of a dense point set (camera coordinates, z forward) into a uint16 depth
+    image in units of depth_scale metres: every point is splatted over (2*splat+1)^2 pixels and
+    the nearest wins; background_z (metres) fills the pixels nothing projects to (a wall behind
+    the objects), 0 leaves them invalid.  For the streaming test and bench; not a product path."""
+    p = np.asarray(points, np.float64)
+    z = p[:, 2]
+    ok = z > 1e-6
+    p, z = p[ok], z[ok]
+    u = np.rint(p[:, 0] * fx / z + cx).astype(np.int64)
+    v = np.rint(p[:, 1] * fy / z + cy).astype(np.int64)
+    raw = np.clip(np.rint(z / depth_scale), 1, 65535).astype(np.int64)
+    img = np.full(width * height, 65536, np.int64)
+    for dv in range(-splat, splat + 1):
+        for du in range(-splat, splat + 1):
+            uu, vv = u + du, v + dv
+            m = (uu >= 0) & (uu < width) & (vv >= 0) & (vv < height)
+            np.minimum.at(img, vv[m] * width + uu[m], raw[m])
+    bg = 0 if background_z is None else int(round(background_z / depth_scale))
+    img[img == 65536] = bg
+    return img.reshape(height, width).astype(np.uint16)

@@ -38,7 +38,7 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = os.path.join(_HERE, "liboracle_ppf.so")
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_ppf.c", "oracle_voxel.c", "oracle_ppf.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_ppf.c", "oracle_voxel.c", "oracle_depth.c", "oracle_ppf.h")]
     if not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
         build()
     L = C.CDLL(path)
@@ -74,6 +74,8 @@ def lib():
     L.orc_ht_dist.argtypes = [vp, vp, vp]
     L.orc_voxel_grid.restype = C.c_long
     L.orc_voxel_grid.argtypes = [vp, vp, C.c_size_t, C.c_float, vp, vp]
+    L.orc_depth_to_cloud.restype = C.c_long
+    L.orc_depth_to_cloud.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [C.c_float] * 8 + [vp, vp]
     L.orc_pose_from_cells.restype = C.c_int
     L.orc_pose_from_cells.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int,
                                       C.c_int, vp]
@@ -250,6 +252,17 @@ def voxel_grid(points, normals, leaf):
     k = lib().orc_voxel_grid(_p(p), _p(n), len(p), float(leaf), _p(po), _p(no))
     if k < 0:
         raise ValueError("leaf size too small for the cloud extent")
+    return po[:k].copy(), no[:k].copy()
+
+
+def depth_to_cloud(depth, fx, fy, cx, cy, depth_scale=0.001, z_min=0.1, z_max=10.0, max_jump=0.05):
+    """Depth image -> (points, normals): this build's own front-end specification (oracle_depth.c);
+    the reference has no such step, so there is nothing to pin it on."""
+    d = np.ascontiguousarray(depth)
+    assert d.dtype in (np.uint16, np.float32) and d.ndim == 2
+    po, no = np.zeros((d.size, 3), np.float32), np.zeros((d.size, 3), np.float32)
+    k = lib().orc_depth_to_cloud(_p(d), int(d.dtype == np.uint16), d.shape[1], d.shape[0], fx, fy, cx, cy,
+                                 depth_scale, z_min, z_max, max_jump, _p(po), _p(no))
     return po[:k].copy(), no[:k].copy()
 
 

@@ -139,3 +139,22 @@ def test_ply_reader_and_writer(built_lib, ppf, synth, tmp_path):
             ppf.ply_read(f)
     with pytest.raises(ppf.OslamError):
         ppf.ply_read(str(tmp_path / "missing.ply"))
+
+
+def test_model_file_rejections_need_no_gpu(built_lib, ppf, tmp_path):
+    """oslam_model_load checks the file before it touches a device: a missing file, a foreign file and
+    another layout version are OSLAM_E_INVALID on any machine."""
+    import struct
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Model.load(str(tmp_path / "missing.oslam"))
+    assert e.value.code == ppf.OSLAM_E_INVALID
+    f = str(tmp_path / "foreign.oslam")
+    open(f, "wb").write(b"ply\nformat ascii 1.0\n" + bytes(200))
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Model.load(f)
+    assert e.value.code == ppf.OSLAM_E_INVALID and "not a model file" in str(e.value)
+    f = str(tmp_path / "oldversion.oslam")
+    open(f, "wb").write(struct.pack("<QII", 0x4c444d4f534c4f00, 1, 0) + bytes(200))
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Model.load(f)
+    assert e.value.code == ppf.OSLAM_E_INVALID and "layout version" in str(e.value)

@@ -89,6 +89,37 @@ def test_accumulator_long_hit_lists(ppf, oracle, built_lib, synth):
         assert np.array_equal(got, want), r
 
 
+def test_model_database_round_trip(ppf, oracle, built_lib, case_two_slices, tmp_path):
+    # a table written with Model.save and mapped back with Model.load votes exactly like the one that
+    # was built (cells, counters and pose identical); a flipped byte in the file is refused
+    c = case_two_slices
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=10)
+    built = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+    T0 = built.ppf_lookup(sc).copy()
+    cells0, _ = built.last_cells()
+    f = str(tmp_path / "m.oslam")
+    built.save(f)
+    loaded = ppf.Model.load(f)
+    assert loaded.numPoints() == built.numPoints() and loaded.d_dist == np.float32(c["d"])
+    assert loaded.table_bytes() == built.table_bytes()
+    T1 = loaded.ppf_lookup(sc)
+    cells1, _ = loaded.last_cells()
+    assert np.array_equal(T0, T1) and cells_equal(cells0, cells1)
+    for k in ("num_hits", "num_votes", "num_unique_votes", "num_model_keys", "max_count"):
+        assert loaded.stats[k] == built.stats[k], k
+    raw = bytearray(open(f, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    g = str(tmp_path / "damaged.oslam")
+    open(g, "wb").write(bytes(raw))
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Model.load(g)
+    assert "checksum" in str(e.value)
+    open(g, "wb").write(bytes(raw[: len(raw) // 3]))
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Model.load(g)
+    assert "truncated" in str(e.value)
+
+
 def _align_and_compare(ppf, oracle, c, df=1, **flags):
     par = ppf.default_params()
     sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=df, params=par)
@@ -450,3 +481,55 @@ def test_random_small_clouds_match_oracle(ppf, oracle, built_lib):
         if len(ocells):
             rc, To = oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)
             assert np.array_equal(T, To), (trial, M, S)
+
+
+def test_depth_front_end_equals_its_statement(ppf, oracle, built_lib, synth):
+    """Depth image -> points + normals (oslam_depth_to_cloud) against oracle/oracle_depth.c, bit for
+    bit, on uint16 and float images with holes, depth edges and a ragged size; a tilted plane gives
+    the plane's normal at every pixel.  The reference has no such step: parity unpinned."""
+    rng = np.random.default_rng(11)
+    h, w = 61, 83
+    v, u = np.mgrid[0:h, 0:w]
+    z = 1.2 + 0.002 * u + 0.004 * v + 0.05 * np.sin(u / 5.0) * np.cos(v / 7.0)
+    z[20:30, 40:55] = 0.6                      # an object in front: depth edges around it
+    z[rng.random((h, w)) < 0.05] = 0           # holes
+    d16 = np.rint(z * 1000).astype(np.uint16)
+    cam = dict(fx=80.0, fy=82.0, cx=41.3, cy=30.1)
+    for img, scale in ((d16, 0.001), (z.astype(np.float32), 1.0)):
+        gp, gn = ppf.depth_to_cloud(img, depth_scale=scale, z_min=0.3, z_max=5.0, max_jump=0.03, **cam)
+        op, on = oracle.depth_to_cloud(img, depth_scale=scale, z_min=0.3, z_max=5.0, max_jump=0.03, **cam)
+        assert 0 < len(gp) < h * w and gp.shape == op.shape
+        assert np.array_equal(gp, op) and np.array_equal(gn, on)
+        assert np.allclose(np.linalg.norm(gn, axis=1), 1, atol=1e-5) and np.all(np.einsum("ij,ij->i", gn, gp) <= 0)
+    # plane a*x + b*y + c*z = d seen by the camera: every normal is -(a, b, c) normalised
+    a, b, c, dd = 0.2, -0.1, 1.0, 2.0
+    x, y = (u - cam["cx"]) / cam["fx"], (v - cam["cy"]) / cam["fy"]
+    zp = (dd / (a * x + b * y + c)).astype(np.float32)
+    gp, gn = ppf.depth_to_cloud(zp, depth_scale=1.0, z_min=0.3, z_max=9.0, max_jump=0.5, **cam)
+    want = -np.float32([a, b, c]) / np.linalg.norm([a, b, c])
+    assert len(gp) == (h - 2) * (w - 2) and np.abs(gn - want).max() < 2e-3
+    with pytest.raises(ppf.OslamError):
+        ppf.depth_to_cloud(d16[:2], **cam)
+
+
+def test_depth_frame_to_pose(ppf, built_lib, synth):
+    """The streaming chain on one frame: a model in front of a wall rendered into a 640x480 depth
+    image -> depth_to_cloud -> voxel grid at leaf = d_dist -> PPF registration recovers the model's
+    pose within the reference's own acceptance test (12 degrees, 0.1 diameters, alignment.cpp:141-144)."""
+    mp, mn = synth.make_model(0, 1500)
+    d = synth.d_dist_for(mp, 0.05)
+    diam = synth.bbox_extent(mp)
+    dense, _ = synth.make_model(0, 400000)
+    rng = synth.SplitMix64(77)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = synth.random_rotation(rng)
+    T[:3, 3] = [0.2, -0.1, 6.0]
+    cam_pts = dense @ T[:3, :3].T + T[:3, 3]
+    img = synth.render_depth(cam_pts, background_z=9.0, splat=1)
+    sp, sn = ppf.depth_to_cloud(img, 525.0, 525.0, 319.5, 239.5, z_min=0.5, z_max=12.0, max_jump=0.08)
+    assert len(sp) > 50000
+    sp, sn = ppf.voxel_grid(sp, sn, leaf=d)
+    mg, mgn = ppf.voxel_grid(mp, mn, leaf=d)
+    Tm = ppf.Model(mg, mgn, d_dist=d).ppf_lookup(ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=2))
+    dt, dr = ppf.ht_dist(Tm, T)
+    assert dr < np.deg2rad(12) and dt < 0.1 * diam, (np.degrees(dr), dt / diam)
