@@ -7,6 +7,7 @@ The directory name contains a hyphen, so import it with
   ppf    -- Model / Scene / ppf_registration over the C-ABI (include/oslam.h)
   synth  -- deterministic synthetic clouds for tests and bench
   dist   -- the multi-GPU exchange step (all-reduce of maxima + all-gather of peaks)
+  evaluate (imported on demand) -- recall vs occlusion, the protocol of the reference's analyze_mian.py
 """
 from . import dist, ppf, synth  # noqa: F401
 from .ppf import Model, Scene, ppf_registration, ht_dist  # noqa: F401

@@ -133,7 +133,8 @@ int main(int argc, char **argv)
     for (i = 0; i < n_scenes; i++)
         for (j = 0; j < n_models; j++) {
             const float *R = T + 16 * (i * n_models + j);
-            fprintf(stderr, "Found transformation (%s in %s):\n", model_files[j], scene_files[i]);
+            /* the two lines analyze_mian.py:19-41 parses (two-token prefix, as Boost.Log's) */
+            fprintf(stderr, "[oslam] [info] Transformations for %s in %s:\n", model_files[j], scene_files[i]);
             for (o = 0; o < 4; o++) fprintf(stderr, "%10.6f %10.6f %10.6f %10.6f\n", R[4 * o], R[4 * o + 1], R[4 * o + 2], R[4 * o + 3]);
             if (n_val) {                                              /* alignment.cpp:300-335 */
                 float truth[16], dist[2];
@@ -147,7 +148,7 @@ int main(int argc, char **argv)
                     const float model_diam = d_dists[j] / tau[j];
                     const float trans_thresh = vt * model_diam, rot_thresh = vr * (float)(M_PI / 180.0);
                     const int match = dist[0] < trans_thresh && dist[1] < rot_thresh;
-                    fprintf(stderr, "Distance (trans, rot): %f, %f; thresholds %f, %f\n", dist[0], dist[1], trans_thresh, rot_thresh);
+                    fprintf(stderr, "[oslam] [info] Distance (trans, rot): %f, %f\n", dist[0], dist[1]);
                     printf("%d\n", match);
                 }
             }

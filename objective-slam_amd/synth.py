@@ -108,13 +108,15 @@ def d_dist_for(points, tau_d):
 
 
 def make_scene(model_ids, n_points, seed, n_instances=1, instance_points=None, noise_sigma=0.0,
-               box_diameters=10.0, n_clutter=None):
+               box_diameters=10.0, n_clutter=None, occlusion=0.0):
     """Scene with `n_instances` posed copies of each model id in `model_ids`.
 
     Returns (points f32 [S,3], normals f32 [S,3], poses) where poses is a list of
     (model_id, 4x4 float64 ground-truth pose, model -> scene).
     The instance points are a fresh sampling of the model surface, not the model
-    cloud itself, as a sensor would see it.
+    cloud itself, as a sensor would see it.  occlusion in [0, 1): that share of every instance's
+    surface samples is cut away on one side (a half space in a random direction, as an occluder
+    in front of the object would); the freed point budget goes to the ground plane.
     """
     rng = SplitMix64(seed)
     diam = 3.5
@@ -127,6 +129,8 @@ def make_scene(model_ids, n_points, seed, n_instances=1, instance_points=None, n
     n_inst_total = min(n_points, instance_points * n_obj)
     n_plane = (n_points - n_inst_total) // 3
     n_clut_total = n_points - n_inst_total - n_plane
+    n_keep = max(8, int(round((n_inst_total // n_obj) * (1.0 - occlusion)))) if occlusion > 0 else n_inst_total // n_obj
+    n_plane += n_obj * (n_inst_total // n_obj - n_keep)
     pts, nrm, poses = [], [], []
     for mid in model_ids:
         for _ in range(n_instances):
@@ -134,6 +138,11 @@ def make_scene(model_ids, n_points, seed, n_instances=1, instance_points=None, n
             t = (rng.uniform(3) * 2 - 1) * half
             t[2] = abs(t[2]) * 0.3 + 1.5
             p, n = sample_surface(mid, n_inst_total // n_obj, rng)
+            if occlusion > 0:
+                dvec = random_rotation(rng)[:, 0]
+                keep = np.argsort(p @ dvec, kind="stable")[:n_keep]
+                keep.sort()
+                p, n = p[keep], n[keep]
             pts.append(p @ R.T + t)
             nrm.append(n @ R.T)
             T = np.eye(4)

@@ -443,7 +443,7 @@ def test_cli_front_end(ppf, built_lib, synth, tmp_path):
     sp2, sn2 = ppf.ply_read(str(tmp_path / "scene.ply"))          # ascii: 9 significant digits
     sg, sgn = ppf.voxel_grid(sp2, sn2, leaf=leaf)
     T = ppf.Model(mg, mgn, d_dist=d).ppf_lookup(ppf.Scene(sg, sgn, d_dist=d, ref_point_downsample_factor=2))
-    lines = r.stderr.split("Found transformation")[1].splitlines()[1:5]
+    lines = r.stderr.split("Transformations for")[1].splitlines()[1:5]
     Tcli = np.array([[float(x) for x in ln.split()] for ln in lines], np.float32)
     np.testing.assert_allclose(Tcli, T, atol=2e-6)
 
