@@ -129,10 +129,16 @@ struct oslam_model {
     oslamk_cell *d_out;
     uint32_t out_cap;
     oslam_cell *h_out;
-    /* last result */
+    /* frames T_g of the model points [M][16] and the point weights, for the pose tail on the device */
+    float *d_Tm16, *d_weights;
+    /* last result: on the host, or still on the device (pose tail ran there) until a tap asks for it */
     oslam_cell *last_cells;
     float *last_poses;
     size_t n_last;
+    int last_on_device;
+    oslamk_cell *d_pose_cells;
+    float *d_pose_T;
+    size_t pose_cap;
     /* host copy of the table for the bucket tap */
     oslamk_slot *h_slots;
 };
@@ -146,6 +152,7 @@ struct oslam_scene {
     int n_ref;
     uint32_t *h_ref_idx, *d_ref_idx;
     float *d_tsg;
+    float *d_Ts16;                    /* frames of every reference-point candidate (index % df == 0, all ranks) */
 };
 
 static int pick_device(int dev_req, int *dev_out)
@@ -298,6 +305,10 @@ void oslam_model_destroy(oslam_model *m)
     if (m->table.reach) (void)hipFree(m->table.reach);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_Tm16) (void)hipFree(m->d_Tm16);
+    if (m->d_weights) (void)hipFree(m->d_weights);
+    if (m->d_pose_cells) (void)hipFree(m->d_pose_cells);
+    if (m->d_pose_T) (void)hipFree(m->d_pose_T);
     free(m->h_out);
     free(m->weights);
     free(m->last_cells);
@@ -621,6 +632,11 @@ int oslam_model_set_point_weights(oslam_model *m, const float *weights, size_t n
 {
     if (!m || !weights || n != (size_t)m->c.n) return fail(OSLAM_E_INVALID, "bad weights");
     memcpy(m->weights, weights, sizeof(float) * n);
+    if (m->d_weights) {
+        if (hipSetDevice(m->dev) != hipSuccess ||
+            hipMemcpy(m->d_weights, m->weights, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(OSLAM_E_DEVICE, "cannot update the weights on the device");
+    }
     return OSLAM_OK;
 }
 
@@ -633,6 +649,7 @@ void oslam_scene_destroy(oslam_scene *s)
     free(s->h_ref_idx);
     if (s->d_ref_idx) (void)hipFree(s->d_ref_idx);
     if (s->d_tsg) (void)hipFree(s->d_tsg);
+    if (s->d_Ts16) (void)hipFree(s->d_Ts16);
     free(s);
 }
 
@@ -850,7 +867,7 @@ done:
 /* vote + D2H of emitted cells; handles an overflowing record buffer by a second,
  * exactly thresholded launch */
 static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, size_t *n_cells,
-                          oslam_stats *st)
+                          oslam_stats *st, size_t leave_on_device_from)
 {
     int rc = OSLAM_OK;
     float ms = 0.0f, ms2 = 0.0f, msv = 0.0f, msk = 0.0f;
@@ -870,7 +887,8 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
                         "peak extraction %llu, inside vote steps %llu\n",
                 cnt->prof[0], cnt->prof[1], cnt->prof[2], cnt->prof[3]);
     *n_cells = cnt->out_count;
-    if (*n_cells) {
+    /* the records stay in HBM when the pose tail runs there (leave_on_device_from = its lower bound, 0 = never) */
+    if (*n_cells && !(leave_on_device_from && *n_cells >= leave_on_device_from)) {
         HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * *n_cells, hipMemcpyDeviceToHost));
     }
     if (st) {
@@ -927,14 +945,122 @@ done:
     return rc;
 }
 
+/* ---- pose tail on the device (oslam_posegpu.hip) for large peak sets ---- */
+static size_t pose_gpu_min(void)
+{
+    const char *e = getenv("OSLAM_POSE_GPU_MIN");        /* tests force the device path at small sizes */
+    return e && atol(e) > 0 ? (size_t)atol(e) : 4096;
+}
+
+/* 0: the tail may run on the device; the host-only variants keep the host path */
+static size_t pose_gpu_from(const oslam_model *m)
+{
+    if (m->params.cpu_clustering || m->params.use_averaged_clusters) return 0;
+    return pose_gpu_min();
+}
+
+static void drop_last(oslam_model *m)
+{
+    free(m->last_cells);
+    free(m->last_poses);
+    m->last_cells = NULL;
+    m->last_poses = NULL;
+    m->n_last = 0;
+    m->last_on_device = 0;
+}
+
+/* frames and weights the device tail reads; built on first use */
+static int pose_tables(oslam_model *m, oslam_scene *s)
+{
+    int rc = OSLAM_OK;
+    float *h = NULL;
+    if (!m->d_Tm16) {
+        const size_t M = (size_t)m->c.n;
+        h = (float *)malloc(sizeof(float) * 16 * M);
+        if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
+        oslam_T_g_full(m->c.h_xyz, m->c.h_nrm, 0, 1, M, h);
+        HIPCHK(hipMalloc((void **)&m->d_Tm16, sizeof(float) * 16 * M));
+        HIPCHK(hipMemcpy(m->d_Tm16, h, sizeof(float) * 16 * M, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&m->d_weights, sizeof(float) * M));
+        HIPCHK(hipMemcpy(m->d_weights, m->weights, sizeof(float) * M, hipMemcpyHostToDevice));
+        free(h);
+        h = NULL;
+    }
+    if (!s->d_Ts16) {
+        const size_t n_all = ((size_t)s->c.n + s->df - 1) / s->df;
+        h = (float *)malloc(sizeof(float) * 16 * n_all);
+        if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
+        oslam_T_g_full(s->c.h_xyz, s->c.h_nrm, 0, s->df, n_all, h);
+        HIPCHK(hipMalloc((void **)&s->d_Ts16, sizeof(float) * 16 * n_all));
+        HIPCHK(hipMemcpy(s->d_Ts16, h, sizeof(float) * 16 * n_all, hipMemcpyHostToDevice));
+    }
+done:
+    free(h);
+    return rc;
+}
+
+/* Pose tail on the device over the n records in m->d_out.  Returns OSLAM_OK with *done = 1 when it
+ * produced the pose; *done = 0 when fewer than two cells survive (the host path handles those). */
+static int finish_on_device(oslam_model *m, oslam_scene *s, size_t n, uint32_t gmax, float T[16], oslam_stats *st,
+                            int *done)
+{
+    int rc = OSLAM_OK, k;
+    static float rot[128];
+    static int rot_ready;
+    uint32_t n_kept = 0, best = 0;
+    const float min_votecount = m->params.vote_count_threshold * gmax;      /* model.cu:164 */
+    *done = 0;
+    rc = pose_tables(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (!rot_ready) { oslam_rotx_table(rot); rot_ready = 1; }
+    if (m->pose_cap < n) {
+        if (m->d_pose_cells) (void)hipFree(m->d_pose_cells);
+        if (m->d_pose_T) (void)hipFree(m->d_pose_T);
+        m->d_pose_cells = NULL;
+        m->d_pose_T = NULL;
+        m->pose_cap = 0;
+        HIPCHK(hipMalloc((void **)&m->d_pose_cells, sizeof(oslamk_cell) * n));
+        HIPCHK(hipMalloc((void **)&m->d_pose_T, sizeof(float) * 16 * n));
+        m->pose_cap = n;
+    }
+    k = oslamk_pose_stage(m->d_out, (uint32_t)n, min_votecount, m->d_Tm16, s->d_Ts16, s->df, m->d_weights, rot, m->d_dist,
+                          m->params.use_l1_norm, m->d_pose_cells, m->d_pose_T, &n_kept, &best, T, g_stream);
+    if (k == -2) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    if (k != 0) return fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k));
+    if (n_kept < 2) return OSLAM_OK;
+    drop_last(m);
+    m->n_last = n_kept;
+    m->last_on_device = 1;
+    if (st) { st->num_top = n_kept; st->max_count = gmax; }
+    *done = 1;
+done:
+    return rc;
+}
+
+/* the taps read the last result from the host: fetch it if it is still on the device */
+static int materialise_last(oslam_model *m)
+{
+    int rc = OSLAM_OK;
+    const size_t n = m->n_last;
+    if (!m->last_on_device) return OSLAM_OK;
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    m->last_cells = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
+    m->last_poses = (float *)malloc(sizeof(float) * 16 * (n ? n : 1));
+    if (!m->last_cells || !m->last_poses) { drop_last(m); return fail(OSLAM_E_NOMEM, "host allocation failed"); }
+    HIPCHK(hipMemcpy(m->last_cells, m->d_pose_cells, sizeof(oslam_cell) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(m->last_poses, m->d_pose_T, sizeof(float) * 16 * n, hipMemcpyDeviceToHost));
+    m->last_on_device = 0;
+done:
+    return rc;
+}
+
 static int finish_cells(oslam_model *m, oslam_scene *s, oslam_cell *cells, size_t n, uint32_t gmax,
                         float T[16], oslam_stats *st)
 {
     int rc;
     n = oslam_filter_cells(cells, n, m->params.vote_count_threshold, gmax);
     oslam_sort_cells(cells, n);
-    free(m->last_cells);
-    free(m->last_poses);
+    drop_last(m);
     m->last_cells = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
     m->last_poses = (float *)calloc(16 * (n ? n : 1), sizeof(float));
     m->n_last = 0;
@@ -966,10 +1092,21 @@ int oslam_align(oslam_model *m, oslam_scene *s, float T[16], oslam_stats *stats)
     if (!stats) stats = &local;
     memset(stats, 0, sizeof *stats);
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
-    rc = vote_and_fetch(m, s, &cnt, &n, stats);
+    rc = vote_and_fetch(m, s, &cnt, &n, stats, pose_gpu_from(m));
     if (rc != OSLAM_OK) return rc;
+    if (pose_gpu_from(m) && n >= pose_gpu_from(m)) {
+        int done = 0;
+        rc = finish_on_device(m, s, n, cnt.gmax, T, stats, &done);
+        if (rc != OSLAM_OK) return rc;
+        if (done) {
+            stats->ms_total = (float)(now_ms() - t0);
+            return OSLAM_OK;
+        }
+        HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * n, hipMemcpyDeviceToHost));
+    }
     rc = finish_cells(m, s, m->h_out, n, cnt.gmax, T, stats);
     stats->ms_total = (float)(now_ms() - t0);
+done:
     return rc;
 }
 
@@ -987,7 +1124,7 @@ int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, siz
     if (!stats) stats = &local;
     memset(stats, 0, sizeof *stats);
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
-    rc = vote_and_fetch(m, s, &cnt, &n, stats);
+    rc = vote_and_fetch(m, s, &cnt, &n, stats, 0);
     if (rc != OSLAM_OK) return rc;
     /* peaks above the local threshold: a superset of what survives the global one */
     n = oslam_filter_cells(m->h_out, n, m->params.vote_count_threshold, cnt.gmax);
@@ -1012,11 +1149,27 @@ int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, 
     if (rc != OSLAM_OK) return rc;
     if (!stats) stats = &local;
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    if (pose_gpu_from(m) && n >= pose_gpu_from(m) && n <= m->out_cap) {
+        /* the gathered union goes back to HBM; codes that do not name a reference point of this scene
+         * and a point of this model are left to the host path, which reports them */
+        size_t i;
+        int ok = 1, done = 0;
+        for (i = 0; i < n && ok; i++) {
+            const uint32_t sr = (uint32_t)(cells[i].code >> 32), mr = ((uint32_t)cells[i].code) >> 6;
+            ok = sr < (uint32_t)s->c.n && sr % s->df == 0 && mr < (uint32_t)m->c.n;
+        }
+        if (ok) {
+            HIPCHK(hipMemcpy(m->d_out, cells, sizeof(oslam_cell) * n, hipMemcpyHostToDevice));
+            rc = finish_on_device(m, s, n, global_max, T, stats, &done);
+            if (rc != OSLAM_OK || done) return rc;
+        }
+    }
     tmp = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
     if (!tmp) return fail(OSLAM_E_NOMEM, "host allocation failed");
     memcpy(tmp, cells, sizeof(oslam_cell) * n);
     rc = finish_cells(m, s, tmp, n, global_max, T, stats);
     free(tmp);
+done:
     return rc;
 }
 
@@ -1217,6 +1370,7 @@ int oslam_last_cells(oslam_model *m, oslam_cell *cells_out, float *poses_out, si
 {
     size_t n;
     if (!m || !n_out) return fail(OSLAM_E_INVALID, "NULL argument");
+    if ((cells_out || poses_out) && materialise_last(m) != OSLAM_OK) return OSLAM_E_DEVICE;
     n = m->n_last < cap ? m->n_last : cap;
     if (cells_out) memcpy(cells_out, m->last_cells, sizeof(oslam_cell) * n);
     if (poses_out) memcpy(poses_out, m->last_poses, sizeof(float) * 16 * n);

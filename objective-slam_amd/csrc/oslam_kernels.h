@@ -162,6 +162,14 @@ int oslamk_cluster_scores(int n, const float *trans, const float *quat, const in
                           const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
                           float *score, void *stream);
 
+/* pose tail on the device (oslam_posegpu.hip): filter, order, poses, clustering scores, winner.
+ * d_Tm16 [M][16] / d_Ts16 [ceil(S/df)][16]: the frames T_g of the model points and of the scene's
+ * reference-point candidates (host libm); h_rotx_cs: oslam_rotx_table.  Returns a hipError_t, -2 = no host memory */
+int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, float min_votecount, const float *d_Tm16,
+                      const float *d_Ts16, uint32_t df, const float *d_weights, const float *h_rotx_cs, float d_dist,
+                      int use_l1, oslamk_cell *d_cells_out, float *d_poses, uint32_t *n_out, uint32_t *best_out,
+                      float T_best[16], void *stream);
+
 /* device self-test: out_acos[i] = pm_acosf(x[i]); out_atan2[i] = pm_atan2f(y[i], x2[i]);
  * out_bin[i] = pc_alpha_bin_exact(...) */
 int oslamk_selftest(const float *x, const float *y, const float *x2, size_t n, float *out_acos,

@@ -25,6 +25,7 @@
 #include <string.h>
 #include <time.h>
 
+#include "oslam_pose_math.h"
 #include "ppf_math.h"
 
 #ifdef _OPENMP
@@ -32,19 +33,13 @@
 #endif
 
 #define POSE_PI PM_PI_F
+static int pose_threads(size_t n);
 #define POSE_D PM_D_ANGLE
 
-/* ---- 4x4 row-major helpers with the reference's evaluation order ---- */
-static void mat_zero(float *T) { memset(T, 0, 16 * sizeof(float)); }
-
-static void mat_mul(const float *A, const float *B, float *C)   /* kernel.cu:211-223 */
-{
-    int i, j, k;
-    mat_zero(C);
-    for (i = 0; i < 4; i++)
-        for (j = 0; j < 4; j++)
-            for (k = 0; k < 4; k++) C[4 * i + j] += A[4 * i + k] * B[4 * k + j];
-}
+/* ---- 4x4 row-major helpers with the reference's evaluation order (shared with the kernels:
+ * oslam_pose_math.h) ---- */
+#define mat_zero pq_mat_zero
+#define mat_mul pq_mat_mul
 
 static float row_dot4(const float *row, float x, float y, float z, float w)   /* :55-57 */
 {
@@ -68,19 +63,7 @@ static void mat_rot(int axis, float theta, float *T)   /* rotx/roty/rotz :181-20
     else { T[0] = c; T[4] = s; T[1] = ms; T[5] = c; T[10] = 1; }
 }
 
-static void mat_inv_rigid(const float *T, float *I)   /* invht :254-299 */
-{
-    float nr[9];
-    int i, j;
-    for (i = 0; i < 3; i++)
-        for (j = 0; j < 3; j++) {
-            I[4 * i + j] = T[4 * j + i];
-            nr[3 * i + j] = -I[4 * i + j];
-        }
-    for (i = 0; i < 3; i++)
-        I[4 * i + 3] = nr[3 * i] * T[3] + nr[3 * i + 1] * T[7] + nr[3 * i + 2] * T[11];
-    I[12] = 0; I[13] = 0; I[14] = 0; I[15] = 1;
-}
+#define mat_inv_rigid pq_mat_inv_rigid
 
 void oslam_build_T_g(const float p[3], const float n[3], float T[16])
 {
@@ -93,6 +76,17 @@ void oslam_build_T_g(const float p[3], const float n[3], float T[16])
     mat_rot(2, -1 * atan2f(ny, nx), rz);
     mat_mul(rz, ry, tmp);
     mat_mul(tmp, tr, T);
+}
+
+/* full frames of n points (idx NULL: points 0..n-1; else point idx0 + i*step), 16 floats each */
+void oslam_T_g_full(const float *xyz, const float *nrm, size_t idx0, size_t step, size_t n, float *out16)
+{
+    long i;
+#pragma omp parallel for schedule(static) num_threads(pose_threads(n))
+    for (i = 0; i < (long)n; i++) {
+        const size_t r = idx0 + (size_t)i * step;
+        oslam_build_T_g(xyz + 3 * r, nrm + 3 * r, out16 + 16 * (size_t)i);
+    }
 }
 
 void oslam_T_g_rows(const float *xyz, const float *nrm, const uint32_t *idx, size_t n,
@@ -153,11 +147,19 @@ static int pose_threads(size_t n)
 static void cell_pose(uint64_t code, const float *Tm, const float *Ts, float *T)
 {
     uint32_t a = ((uint32_t)code) & 63u;
-    float rx[16], inv[16], tmp[16];
-    mat_rot(0, a * POSE_D - POSE_PI, rx);
-    mat_inv_rigid(Ts, inv);
-    mat_mul(inv, rx, tmp);
-    mat_mul(tmp, Tm, T);
+    float th = a * POSE_D - POSE_PI;
+    pq_cell_pose(Tm, Ts, cosf(th), sinf(th), T);
+}
+
+/* cos and sin of the 64 rotations about x a vote code can name (the kernels' table) */
+void oslam_rotx_table(float cs[128])
+{
+    uint32_t a;
+    for (a = 0; a < 64; a++) {
+        float th = a * POSE_D - POSE_PI;
+        cs[2 * a] = cosf(th);
+        cs[2 * a + 1] = sinf(th);
+    }
 }
 
 /* T_g of every distinct point index that occurs in the cells, computed once each (many cells
@@ -203,29 +205,10 @@ static const float *frame_cache_get(const frame_cache *fc, uint32_t idx)
     return fc->T + 16 * lo;
 }
 
-/* ---- K7 (kernel.cu:128-144): q = (w,x,y,z) ---- */
-static void pose_quat(const float *T, float q[4])
-{
-    float t = T[0] + T[5] + T[10];
-    float r = sqrtf(1 + t), n;
-    q[0] = 0.5f * r;
-    q[1] = copysignf(0.5f * sqrtf(1 + T[0] - T[5] - T[10]), T[9] - T[6]);
-    q[2] = copysignf(0.5f * sqrtf(1 - T[0] + T[5] - T[10]), T[2] - T[8]);
-    q[3] = copysignf(0.5f * sqrtf(1 - T[0] - T[5] + T[10]), T[4] - T[1]);
-    n = sqrtf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-}
-
-/* ---- K8: translation cell and its FNV key (kernel.cu:663-699) ---- */
-static float quant_down(float x, float y) { return x - fmodf(x, y); }
-
-static uint32_t fnv_cell(const int32_t c[3])
-{
-    uint32_t h = PM_FNV_BASIS;
-    int i;
-    for (i = 0; i < 3; i++) h = pm_fnv1a_word(h, (uint32_t)c[i]);
-    return h;
-}
+/* ---- K7, K8: oslam_pose_math.h ---- */
+#define pose_quat pq_pose_quat
+#define quant_down pq_quant_down
+#define fnv_cell pq_fnv_cell
 
 typedef struct { uint32_t hash; uint32_t idx; } hash_idx;
 static int hash_idx_order(const void *a, const void *b)

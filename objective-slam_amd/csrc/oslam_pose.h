@@ -20,6 +20,12 @@ extern "C" {
 void oslam_T_g_rows(const float *xyz, const float *nrm, const uint32_t *idx, size_t n,
                     float *rows_out);
 
+/* the whole frame T_g (16 floats, row-major) of the points idx0, idx0 + step, ... (n of them) */
+void oslam_T_g_full(const float *xyz, const float *nrm, size_t idx0, size_t step, size_t n, float *out16);
+
+/* cos, sin of alpha_idx * D - pi for alpha_idx = 0..63 (libm): the kernels' rotation table */
+void oslam_rotx_table(float cs[128]);
+
 /* Optional accelerator for the clustering scores (set by oslam_host.c while a device is bound):
  * fills score[n] exactly as the host loop would, returns 0 on success.  hash_idx = n pairs
  * {cell hash, pose index} ascending. */

@@ -533,3 +533,62 @@ def test_depth_frame_to_pose(ppf, built_lib, synth):
     Tm = ppf.Model(mg, mgn, d_dist=d).ppf_lookup(ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=2))
     dt, dr = ppf.ht_dist(Tm, T)
     assert dr < np.deg2rad(12) and dt < 0.1 * diam, (np.degrees(dr), dt / diam)
+
+
+@pytest.fixture
+def pose_tail_on_device(monkeypatch):
+    # the device pose tail (oslam_posegpu.hip) normally starts at 4096 peak records; run it from 2
+    monkeypatch.setenv("OSLAM_POSE_GPU_MIN", "2")
+
+
+def test_device_pose_tail_equals_oracle(ppf, oracle, built_lib, case_small, case_two_slices, synth, pose_tail_on_device):
+    """Filter, order, K5..K9 and the winner on the GPU: kept cells (in order), every pose matrix and the
+    returned pose equal the oracle's, as the host tail's do; also with the l1 flag, with point
+    weights, with two model slices, through the sharded align_finish, and when only one cell survives
+    (which the device path hands back to the host)."""
+    for c, df, flags in ((case_small, 1, {}), (case_small, 3, dict(use_l1_norm=True)), (case_two_slices, 10, {})):
+        _align_and_compare(ppf, oracle, c, df=df, **flags)
+    c = case_small
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"])
+    mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+    mo.ppf_lookup(sc)
+    cells, poses = mo.last_cells()
+    assert len(cells) > 50
+    ocells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 1, c["d"], 0.4)
+    assert cells_equal(cells, ocells)
+    assert np.array_equal(poses, oracle.trans_calc2(ocells, c["mp"], c["mn"], c["sp"], c["sn"]))
+    # weights change the clustering scores (kernel.cu:777)
+    w = np.linspace(0.1, 3.0, len(c["mp"])).astype(np.float32)
+    mo.SetModelPointVoteWeights(w)
+    Tw = mo.ppf_lookup(sc)
+    Th, _ = ppf.pose_stage(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], weights=w)
+    assert np.array_equal(Tw, Th)
+    # sharded: three local peak lists -> union -> align_finish on the device
+    all_cells, gmax = [], 0
+    for rank in range(3):
+        par = ppf.default_params(shard_rank=rank, shard_world=3)
+        scr = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=2, params=par)
+        mor = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
+        cl, lmax = mor.align_local(scr, cap=1 << 16)
+        all_cells.append(cl)
+        gmax = max(gmax, lmax)
+    T = mor.align_finish(scr, np.concatenate(all_cells), gmax)
+    oc2, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 2, c["d"], 0.4)
+    _, To = oracle.pose_from_cells(oc2, c["mp"], c["mn"], c["sp"], c["sn"], c["d"])
+    assert cells_equal(mor.last_cells()[0], oc2) and np.array_equal(T, To)
+    # a threshold that leaves one cell: the reference's kernels return early and the pose is zero
+    one = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], vote_count_threshold=0.999)
+    T1 = one.ppf_lookup(sc)
+    assert one.stats["num_top"] == 1 and np.all(T1 == 0)
+
+
+def test_device_pose_tail_random_clouds(ppf, oracle, built_lib, pose_tail_on_device):
+    rng = np.random.default_rng(977)
+    for trial in range(10):
+        M, S = int(rng.choice([17, 64, 333, 1100])), int(rng.choice([65, 257, 700, 1500]))
+        mp = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+        mn = (rng.normal(size=(M, 3)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+        sp = np.concatenate([mp[: min(M, S // 2)] + np.float32(0.3), rng.uniform(-2, 2, (S - min(M, S // 2), 3))]).astype(np.float32)
+        sn = np.concatenate([mn[: min(M, S // 2)], rng.normal(size=(S - min(M, S // 2), 3))]).astype(np.float32)
+        _align_and_compare(ppf, oracle, dict(mp=mp, mn=mn, sp=sp, sn=sn, d=float(rng.choice([0.1, 0.25]))),
+                           df=int(rng.choice([1, 2, 5])))

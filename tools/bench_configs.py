@@ -1,0 +1,131 @@
+"""Secondary measurements on one MI355X: BASELINE.json configs[1..4] (bench.py measures the headline
+configuration; these are not bench lines).  Needs a HIP device.
+
+  python tools/bench_configs.py cfg2     single 5k model vs 50k voxel-gridded scene
+  python tools/bench_configs.py cfg3     10-model database vs 100k scene, all tables resident
+  python tools/bench_configs.py cfg4     a 1-GPU slice of the 100-model / 500k-scene job: this rank's
+                                         share (1/8 of the reference points) of N models, ref_point_df 20
+  python tools/bench_configs.py cfg5     streaming: 640x480 depth frames -> points+normals -> voxel grid
+                                         -> registration against a resident model database; frames/s
+One JSON line each."""
+import importlib, json, os, sys, time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("objective-slam_amd")
+ppf, synth = pkg.ppf, pkg.synth
+
+
+def found_at_reference_criterion(T, truth, pts):
+    dt, dr = ppf.ht_dist(T, truth)
+    return bool(dr < np.radians(12) and dt < 0.1 * synth.bbox_extent(pts))
+
+
+def align_all(models, dd, sp, sn, df, params=None):
+    out = []
+    for mo, d in zip(models, dd):
+        sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df, params=params)
+        out.append((mo.ppf_lookup(sc, allow_no_votes=True).copy(), dict(mo.stats)))
+        sc.close()
+    return out
+
+
+def cfg2():
+    mp, mn = synth.make_model(0, 5000)
+    d = synth.d_dist_for(mp, 0.025)
+    raw_p, raw_n, poses = synth.make_scene([0], 200000, 2002, instance_points=20000, noise_sigma=0.1 * d)
+    t = time.perf_counter(); sp, sn = ppf.voxel_grid(raw_p, raw_n, leaf=0.6 * d); t_vox = time.perf_counter() - t
+    mo = ppf.Model(mp, mn, d_dist=d)
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=5)
+    mo.ppf_lookup(sc)
+    t = time.perf_counter(); T = mo.ppf_lookup(sc); el = time.perf_counter() - t
+    st = mo.stats
+    return {"config": "cfg2: 5k model vs voxel-gridded scene", "scene_points_after_voxel_grid": len(sp), "voxel_grid_s": t_vox,
+            "ref_point_df": 5, "align_s": el, "scene_ppfs_per_s": st["num_scene_ppfs"] / el, "votes_per_s": st["num_votes"] / el,
+            "found": found_at_reference_criterion(T, poses[0][1], mp)}
+
+
+def cfg3():
+    ids = list(range(10))
+    clouds = [synth.make_model(k, 5000) for k in ids]
+    dd = [synth.d_dist_for(c[0], 0.025) for c in clouds]
+    sp, sn, poses = synth.make_scene([0, 4, 8], 100000, 2003, instance_points=5000, noise_sigma=0.1 * dd[0])
+    t = time.perf_counter(); models = [ppf.Model(c[0], c[1], d_dist=d) for c, d in zip(clouds, dd)]; t_build = time.perf_counter() - t
+    align_all(models[:1], dd[:1], sp, sn, 10)
+    t = time.perf_counter(); res = align_all(models, dd, sp, sn, 10); el = time.perf_counter() - t
+    return {"config": "cfg3: 10-model database vs 100k scene", "db_models": 10, "ref_point_df": 10,
+            "db_bytes_in_hbm": sum(m.table_bytes() for m in models), "build_all_s": t_build, "frame_s": el,
+            "scene_ppfs_per_s": sum(s["num_scene_ppfs"] for _, s in res) / el, "votes_per_s": sum(s["num_votes"] for _, s in res) / el,
+            "instances_found": {mid: found_at_reference_criterion(res[mid][0], T, clouds[mid][0]) for mid, T in poses}}
+
+
+def cfg4(n_models=4):
+    ids = list(range(n_models))
+    clouds = [synth.make_model(k, 5000) for k in ids]
+    dd = [synth.d_dist_for(c[0], 0.025) for c in clouds]
+    sp, sn, poses = synth.make_scene(ids[:2], 500000, 2004, instance_points=5000, noise_sigma=0.1 * dd[0])
+    par = ppf.default_params(shard_rank=0, shard_world=8)          # this GPU's eighth of the reference points
+    models = [ppf.Model(c[0], c[1], d_dist=d, params=par) for c, d in zip(clouds, dd)]
+    t = time.perf_counter(); res = align_all(models, dd, sp, sn, 20, params=par); el = time.perf_counter() - t
+    ppfs = sum(s["num_scene_ppfs"] for _, s in res)
+    return {"config": "cfg4 slice: %d of 100 models vs 500k scene, rank 0 of 8 (1/8 of the reference points), local votes + "
+                      "host stage on the local peaks only" % n_models, "ref_point_df": 20,
+            "ref_points_this_rank": int(res[0][1]["num_scene_ppfs"] // (len(sp) - 1)), "seconds_per_model": el / n_models,
+            "projected_seconds_for_100_models_per_gpu": 100 * el / n_models, "scene_ppfs_per_s": ppfs / el,
+            "votes_per_s": sum(s["num_votes"] for _, s in res) / el,
+            "vote_launches_per_model": res[0][1]["vote_launches"]}
+
+
+def cfg5(n_models=4, frames=8):
+    ids = list(range(0, 2 * n_models, 2))
+    clouds = [synth.make_model(k, 1500) for k in ids]
+    dd = [synth.d_dist_for(c[0], 0.05) for c in clouds]
+    grids = [ppf.voxel_grid(c[0], c[1], leaf=d) for c, d in zip(clouds, dd)]
+    models = [ppf.Model(g[0], g[1], d_dist=d) for g, d in zip(grids, dd)]
+    dense = [synth.make_model(k, 300000)[0] for k in ids[:2]]
+    rng = synth.SplitMix64(55)
+    imgs, truths = [], []
+    for f in range(frames):                                    # two objects drifting in front of a wall
+        pts, tr = [], []
+        for j, dn in enumerate(dense):
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :3] = synth.random_rotation(rng)
+            T[:3, 3] = [-2.0 + 4.0 * j + 0.05 * f, 0.3 * j - 0.1, 7.0 + 0.5 * j]
+            pts.append(dn @ T[:3, :3].T + T[:3, 3])
+            tr.append(T)
+        imgs.append(synth.render_depth(np.concatenate(pts), background_z=10.0, splat=1))
+        truths.append(tr)
+    def one(img):
+        t0 = time.perf_counter()
+        sp, sn = ppf.depth_to_cloud(img, 525.0, 525.0, 319.5, 239.5, z_min=0.5, z_max=12.0, max_jump=0.08)
+        t1 = time.perf_counter()
+        out, t_vox, t_al, votes = [], 0.0, 0.0, 0
+        cache = {}
+        for mo, d in zip(models, dd):
+            if d not in cache:                                     # one voxel grid per distinct leaf
+                tv = time.perf_counter(); cache[d] = ppf.voxel_grid(sp, sn, leaf=d); t_vox += time.perf_counter() - tv
+            g = cache[d]
+            ta = time.perf_counter()
+            sc = ppf.Scene(g[0], g[1], d_dist=d, ref_point_downsample_factor=2)
+            out.append(mo.ppf_lookup(sc, allow_no_votes=True).copy())
+            sc.close()
+            t_al += time.perf_counter() - ta
+            votes += mo.stats["num_votes"]
+            if os.environ.get("OSLAM_BENCH_VERBOSE"):
+                print("model d=%.4f scene %d: %.2f ms, stats %s" % (d, len(g[0]), 1e3 * (time.perf_counter() - ta), mo.stats), file=sys.stderr)
+        return out, t1 - t0, t_vox, time.perf_counter() - t0, len(sp), len(g[0]), t_al, votes
+    one(imgs[0])
+    t = time.perf_counter(); res = [one(im) for im in imgs]; el = time.perf_counter() - t
+    ok = sum(found_at_reference_criterion(r[0][j], truths[f][j], clouds[j][0]) for f, r in enumerate(res) for j in range(2))
+    return {"config": "cfg5: 640x480 depth frames vs a %d-model database (host hand-offs between the stages)" % n_models,
+            "frames": frames, "frames_per_s": frames / el, "ms_per_frame": 1e3 * el / frames,
+            "ms_depth_to_cloud": 1e3 * np.mean([r[1] for r in res]), "ms_voxel_grids": 1e3 * np.mean([r[2] for r in res]),
+            "ms_registration_all_models": 1e3 * np.mean([r[6] for r in res]), "votes_per_frame": int(np.mean([r[7] for r in res])),
+            "points_per_frame": int(np.mean([r[4] for r in res])), "scene_points_after_voxel_grid": int(np.mean([r[5] for r in res])),
+            "objects_found": "%d of %d" % (ok, 2 * frames)}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+    print(json.dumps({"cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[which]()), flush=True)

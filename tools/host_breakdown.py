@@ -1,15 +1,17 @@
-"""Scratch: where the non-kernel time of oslam_align goes (5k x 100k)."""
+"""Scratch: where the time of a small registration goes (scene create, align, kernels)."""
 import importlib, sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("objective-slam_amd")
 ppf, synth = pkg.ppf, pkg.synth
-mp, mn = synth.make_model(0, 5000); d = synth.d_dist_for(mp, 0.025)
-sp, sn, poses = synth.make_scene([0], 100000, 2002, instance_points=5000, noise_sigma=0.1 * d)
+M, S, df = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+mp, mn = synth.make_model(0, M); d = synth.d_dist_for(mp, 0.05)
+sp, sn, poses = synth.make_scene([0], S, 2002, instance_points=M, noise_sigma=0.05 * d)
 mo = ppf.Model(mp, mn, d_dist=d)
-t = time.perf_counter(); sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=8); print("scene_create ms", 1e3 * (time.perf_counter() - t))
-for _ in range(3):
-    mo.ppf_lookup(sc); st = mo.stats
-    print("total %.1f kernels %.1f (vote %.1f key %.1f) other %.1f" % (st["ms_total"], st["ms_vote"], st["ms_vote_kernel"], st["ms_key_kernel"], st["ms_total"] - st["ms_vote"]))
-cells, _ = mo.last_cells()
-t = time.perf_counter(); ppf.pose_stage(cells, mp, mn, sp, sn, d); print("pose_stage ms", 1e3 * (time.perf_counter() - t), len(cells))
+for it in range(4):
+    t = time.perf_counter(); sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df); t_sc = time.perf_counter() - t
+    t = time.perf_counter(); mo.ppf_lookup(sc); t_al = time.perf_counter() - t
+    st = mo.stats
+    print("scene_create %.2f ms, align %.2f ms (oslam total %.2f, events %.2f: vote kernel %.2f key+sort %.2f), launches %d, cells %d"
+          % (1e3 * t_sc, 1e3 * t_al, st["ms_total"], st["ms_vote"], st["ms_vote_kernel"], st["ms_key_kernel"], st["vote_launches"], st["num_top"]))
+    sc.close()
