@@ -205,12 +205,15 @@ def main():
 
 def pmc_traffic(args, M, S, df):
     """HBM bytes per vote-kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as
+    (profiles/rNN_pmc_traffic.json of the latest round; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as
     read), or None when no pass for this workload is on file.  Counters cannot be read from
     inside the timed process, so this is the one roofline field that is not measured live."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
+        return None
     try:
-        with open(path) as f:
+        with open(files[-1]) as f:          # the latest round's passes
             rec = json.load(f)
     except (OSError, ValueError):
         return None
