@@ -105,7 +105,8 @@ def main():
         cells, lmax = model.align_local(scene, cap=pkg.dist.LOCAL_CAP)      # vote kernels on this shard
         st = dict(model.stats)
         allrec, gmax = pkg.dist.gather_peaks(cells, lmax, xdev)             # RCCL all-reduce + all-gather
-        T = model.align_finish(scene, allrec, gmax)                          # host-side clustering
+        T = model.align_finish(scene, allrec, gmax)                          # pose tail on the union
+        st["num_top"] = model.stats["num_top"]
         return T, st
 
     def sync():

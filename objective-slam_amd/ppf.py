@@ -264,6 +264,8 @@ class Model:
         if not (allow_no_votes and rc == OSLAM_E_NO_VOTES):
             _check(rc)
         self.best_T = T.reshape(4, 4)
+        if self.stats is not None:                      # the local counters stay; the union's tail adds its own
+            self.stats["num_top"], self.stats["max_count"] = st.num_top, st.max_count
         return self.best_T
 
     # -- result fields of the reference's Model (model.h:92-113) --
