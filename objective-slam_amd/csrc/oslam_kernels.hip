@@ -240,18 +240,19 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
-/* v_mul_hi_u32_u24 / v_mul_u32_u24 by PC_T24_SCALE, written out so that the compiler keeps the
- * two halves apart (from the C expression it builds a 64-bit shift of both) */
+/* v_mul_hi_u32_u24 / v_mul_u32_u24 by PC_T24_SCALE.  The C expressions select exactly these two
+ * instructions; the empty asm keeps the compiler from fusing (hi << 2) and lo into a 64-bit shift
+ * (v_alignbit + v_and) and, unlike instructions written in asm, costs no padding s_nop. */
 __device__ __forceinline__ uint32_t mul24_hi_7680(uint32_t a)
 {
-    uint32_t r;
-    asm("v_mul_hi_u32_u24 %0, 0x1e00, %1" : "=v"(r) : "v"(a));
+    uint32_t r = (uint32_t)(((unsigned long long)(a & 0xffffffu) * PC_T24_SCALE) >> 32);
+    asm("" : "+v"(r));
     return r;
 }
 __device__ __forceinline__ uint32_t mul24_lo_7680(uint32_t a)
 {
-    uint32_t r;
-    asm("v_mul_u32_u24 %0, 0x1e00, %1" : "=v"(r) : "v"(a));
+    uint32_t r = (uint32_t)((unsigned long long)(a & 0xffffffu) * PC_T24_SCALE);
+    asm("" : "+v"(r));
     return r;
 }
 /* a value every lane holds, moved to scalar registers */
@@ -365,10 +366,14 @@ struct VoteRegs {
             }
         }
     }
-    /* FULL: all 256 entries of the chunk exist, no lane needs the trash word */
-    template <bool FULL>
+    /* FULL: all 256 entries of the chunk exist, no lane needs the trash word.  FORCED: some hit of the
+     * piece (or the whole bucket) carries the marker and has every vote re-evaluated; the common
+     * variant has no trace of that in its loop: readlane + 19 vector + compare/branch + 4 LDS atomics
+     * + loop control per hit (256 votes). */
+    template <bool FULL, bool FORCED>
     __device__ __forceinline__ void vote_impl(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                              const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
+                                              const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane,
+                                              unsigned long long fmask) const
     {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t24(th);
@@ -380,10 +385,7 @@ struct VoteRegs {
             rowb[j] = (w[j] >> 15) & 0x1ff80u;
             if (!FULL) rowb[j] = 4u * (uint32_t)lane + j < d.left ? rowb[j] : 4u * (ACC_TRASH + (uint32_t)lane);
         }
-        /* hits whose every vote is re-evaluated: all of them when the bucket holds a marker */
-        const unsigned long long fmask =
-            MODE == 0 ? (d.bforced ? ~0ull : __ballot(th == PC_T22_FORCE) & ((2ull << (d.R - 1u)) - 1ull)) : 0ull;
-        for (int i = d.i0; i < d.i1; i++) {
+        auto one_hit = [&](int i) {
             const uint32_t csm = readlane_u(csmv, i);
             uint32_t tm[4], addr[4];
 #pragma unroll
@@ -399,20 +401,25 @@ struct VoteRegs {
 #pragma unroll
                 for (int j = 0; j < 4; j++) pos[j] = mul24_lo_7680(tm[j]);
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
-                const bool forced = (fmask >> i) & 1ull;
+                const bool forced = FORCED && ((fmask >> i) & 1ull);
                 if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
                     queue_edge_votes(a, hits, acc, tbl, sq, d.entry0, d.hbase + (uint32_t)i, d.left, forced, pos, addr, lane);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(acc) + addr[j]), 1u);
-        }
+        };
+        for (int i = d.i0; i < d.i1; i++) one_hit(i);
     }
     __device__ __forceinline__ void vote(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
                                          const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
     {
-        if (d.left >= 4u * WAVE) vote_impl<true>(a, hits, acc, tbl, sq, d, lane);
-        else vote_impl<false>(a, hits, acc, tbl, sq, d, lane);
+        /* hits whose every vote is re-evaluated: all of them when the bucket holds a marker */
+        const unsigned long long fmask =
+            MODE == 0 ? (d.bforced ? ~0ull : __ballot(th == PC_T22_FORCE) & ((2ull << (d.R - 1u)) - 1ull)) : 0ull;
+        if (MODE == 0 && fmask) vote_impl<false, true>(a, hits, acc, tbl, sq, d, lane, fmask);
+        else if (d.left >= 4u * WAVE) vote_impl<true, false>(a, hits, acc, tbl, sq, d, lane, 0ull);
+        else vote_impl<false, false>(a, hits, acc, tbl, sq, d, lane, 0ull);
     }
 };
 

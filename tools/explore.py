@@ -12,7 +12,7 @@ par = ppf.default_params(vote_mode=mode)
 t = time.time(); mo = ppf.Model(mp, mn, d_dist=d, params=par); print("model build", time.time() - t, flush=True)
 t = time.time(); sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df, params=par); print("scene create", time.time() - t, flush=True)
 for it in range(3):
-    t = time.time(); T = mo.ppf_lookup(sc); el = time.time() - t
+    t = time.time(); T = mo.ppf_lookup(sc, allow_no_votes=True); el = time.time() - t
     st = mo.stats
     print("align %.3fs vote %.1fms ppfs/s %.3e votes/s %.3e" % (el, st["ms_vote"], st["num_scene_ppfs"] / el, st["num_votes"] / el), st, flush=True)
 print(ppf.ht_dist(T, poses[0][1]))
