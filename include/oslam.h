@@ -117,7 +117,10 @@ int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint
 int oslam_model_set_point_weights(oslam_model *m, const float *weights, size_t n);
 
 /* Scene::Scene (include/scene.h:15-16, src/cuda/scene.cu:24-55).  d_dist must
- * equal the d_dist of the model it is aligned with (src/cuda/ppf.cu:64-67). */
+ * equal the d_dist of the model it is aligned with (src/cuda/ppf.cu:64-67), or be 0: the
+ * reference discretises the scene's pair features with d_dist when the Scene is built, here the
+ * scene holds points and reference frames only, so one scene with d_dist 0 serves a database of
+ * models with different d_dist (the pair keys are made per model inside oslam_align). */
 int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
                        float d_dist, unsigned ref_point_downsample_factor,
                        const oslam_params *params, oslam_scene **out);

@@ -664,7 +664,7 @@ int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stri
 
     if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
     *out = NULL;
-    if (!xyz || !nrm || stride_bytes < 12 || !(d_dist > 0.0f) || df == 0) return fail(OSLAM_E_INVALID, "bad scene arguments");
+    if (!xyz || !nrm || stride_bytes < 12 || !(d_dist >= 0.0f) || df == 0) return fail(OSLAM_E_INVALID, "bad scene arguments");
     if (n < 2) return fail(OSLAM_E_INVALID, "scene needs at least 2 points");
     if (n > 0x7fffffffu) return fail(OSLAM_E_LIMIT, "scene too large");
     if (params) p = *params; else oslam_params_default(&p);
@@ -709,7 +709,8 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
 {
     if (!m || !s) return fail(OSLAM_E_INVALID, "NULL handle");
     if (m->dev != s->dev) return fail(OSLAM_E_INVALID, "model and scene live on different devices");
-    if (m->d_dist != s->d_dist) return fail(OSLAM_E_INVALID, "scene d_dist differs from the model's (ppf.cu:64-67)");
+    /* d_dist 0 = a scene for models of any d_dist: nothing a scene holds here depends on it */
+    if (s->d_dist != 0.0f && m->d_dist != s->d_dist) return fail(OSLAM_E_INVALID, "scene d_dist differs from the model's (ppf.cu:64-67)");
     return OSLAM_OK;
 }
 

@@ -108,6 +108,37 @@ __global__ void k_pose_gather(const uint32_t *order, uint32_t n, const float *qu
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+/* work space of the tail, one per device, grown on demand and kept (allocating and freeing ~130 B per
+ * record on every call costs more than the kernels at 10^5 records) */
+struct pose_pool {
+    char *d;
+    size_t cap;
+    void *tmp;
+    size_t tmp_cap;
+};
+static pose_pool g_pool[64];
+
+static int pool_reserve(pose_pool *p, size_t bytes, size_t tmp_bytes)
+{
+    if (p->cap < bytes) {
+        if (p->d) (void)hipFree(p->d);
+        p->d = NULL;
+        p->cap = 0;
+        hipError_t e = hipMalloc((void **)&p->d, bytes + bytes / 4);
+        if (e != hipSuccess) return (int)e;
+        p->cap = bytes + bytes / 4;
+    }
+    if (p->tmp_cap < tmp_bytes) {
+        if (p->tmp) (void)hipFree(p->tmp);
+        p->tmp = NULL;
+        p->tmp_cap = 0;
+        hipError_t e = hipMalloc(&p->tmp, tmp_bytes + tmp_bytes / 4);
+        if (e != hipSuccess) return (int)e;
+        p->tmp_cap = tmp_bytes + tmp_bytes / 4;
+    }
+    return 0;
+}
+
 /* d_cells_in[n_in]: emitted peak records (device).  Outputs (device, caller-owned, capacity n_in):
  * d_cells_out = the kept cells in (count desc, code asc) order, d_poses = 16 floats per kept cell.
  * Host outputs: *n_out kept cells, *best_out index of the winning pose, T_best its matrix with the
@@ -123,11 +154,15 @@ extern "C" int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, f
     char *d = NULL;
     void *d_tmp = NULL;
     float *h_score = NULL;
+    int dev = 0;
+    pose_pool *pool;
     uint32_t n = 0;
     size_t tmp_sel = 0, tmp_s64 = 0, tmp_s32 = 0, tmp_bytes;
     *n_out = 0;
     *best_out = 0;
     if (n_in == 0) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    pool = &g_pool[dev];
     {
         /* one allocation, carved */
         const size_t N = n_in;
@@ -151,7 +186,17 @@ extern "C" int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, f
         const size_t o_sw = off; off += align_up(4 * N);
         const size_t o_score = off; off += align_up(4 * N);
         const size_t o_rot = off; off += align_up(128 * 4);
-        PCHK(hipMalloc((void **)&d, off));
+        PCHK(rocprim::select(nullptr, tmp_sel, d_cells_in, (oslamk_cell *)nullptr, (uint32_t *)nullptr, N, cell_above{min_votecount}, stream));
+        PCHK(rocprim::radix_sort_pairs(nullptr, tmp_s64, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                       (uint32_t *)nullptr, (uint32_t *)nullptr, N, 0, 64, stream));
+        PCHK(rocprim::radix_sort_pairs_desc(nullptr, tmp_s32, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                            (unsigned long long *)nullptr, (unsigned long long *)nullptr, N, 0, 32, stream));
+        tmp_bytes = tmp_sel > tmp_s64 ? tmp_sel : tmp_s64;
+        tmp_bytes = tmp_bytes > tmp_s32 ? tmp_bytes : tmp_s32;
+        rc = pool_reserve(pool, off, tmp_bytes ? tmp_bytes : 16);
+        if (rc != 0) goto done;
+        d = pool->d;
+        d_tmp = pool->tmp;
         oslamk_cell *sel = (oslamk_cell *)(d + o_sel);
         uint32_t *d_count = (uint32_t *)(d + o_cnt);
         unsigned long long *codeA = (unsigned long long *)(d + o_codeA), *codeB = (unsigned long long *)(d + o_codeB);
@@ -164,12 +209,6 @@ extern "C" int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, f
         float *rot = (float *)(d + o_rot);
         cell_above pred = {min_votecount};
 
-        PCHK(rocprim::select(nullptr, tmp_sel, d_cells_in, sel, d_count, N, pred, stream));
-        PCHK(rocprim::radix_sort_pairs(nullptr, tmp_s64, codeA, codeB, cntA, cntB, N, 0, 64, stream));
-        PCHK(rocprim::radix_sort_pairs_desc(nullptr, tmp_s32, cntB, cntA, codeB, codeA, N, 0, 32, stream));
-        tmp_bytes = tmp_sel > tmp_s64 ? tmp_sel : tmp_s64;
-        tmp_bytes = tmp_bytes > tmp_s32 ? tmp_bytes : tmp_s32;
-        PCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
 
         PCHK(rocprim::select(d_tmp, tmp_sel, d_cells_in, sel, d_count, N, pred, stream));
         PCHK(hipMemcpyAsync(&n, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -209,7 +248,5 @@ extern "C" int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, f
     }
 done:
     free(h_score);
-    if (d) (void)hipFree(d);
-    if (d_tmp) (void)hipFree(d_tmp);
     return rc;
 }

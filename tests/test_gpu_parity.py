@@ -198,8 +198,10 @@ def test_no_match_and_bad_arguments(ppf, built_lib, synth):
         mo.ppf_lookup(sc)                       # OSLAM_E_NO_VOTES is reported, not swallowed
     with pytest.raises(ppf.OslamError):
         ppf.Model(mp[:1], mn[:1], d_dist=d)     # n < 2
+    # d_dist 0 makes a scene for models of any d_dist; a negative one is a bad argument
+    assert np.all(mo.ppf_lookup(ppf.Scene(sp, sn, d_dist=0.0), allow_no_votes=True) == 0)
     with pytest.raises(ppf.OslamError):
-        ppf.Scene(sp, sn, d_dist=0.0)
+        ppf.Scene(sp, sn, d_dist=-1.0)
     sc2 = ppf.Scene(sp, sn, d_dist=2 * d)
     with pytest.raises(ppf.OslamError):
         mo.ppf_lookup(sc2)                      # d_dist mismatch (ppf.cu:64-67)
