@@ -407,6 +407,7 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     if (m->params.vote_mode != OSLAM_VOTE_FAST)
         HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
     KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->ent, g_stream));
+    if (!getenv("OSLAM_NO_SPREAD")) KCHK(oslamk_bucket_spread(m->table, m->ent, g_stream));   /* the switch is for A/B measurements */
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
 
     m->out_cap = m->params.max_cells;
@@ -1203,16 +1204,15 @@ int oslam_ppf_registration(const float *const *scene_xyz, const float *const *sc
     for (j = 0; j < n_models && rc == OSLAM_OK; j++)
         rc = oslam_model_create(model_xyz[j], model_nrm[j], model_n[j], stride_bytes, model_d_dists[j], &p, &models[j]);
     for (i = 0; i < n_scenes && rc == OSLAM_OK; i++) {
+        /* one scene object for all models: the reference prepares the scene per model because its
+         * pair keys depend on the model's d_dist (ppf.cu:64-67); here they are made inside the align */
+        oslam_scene *sc = NULL;
+        rc = oslam_scene_create(scene_xyz[i], scene_nrm[i], scene_n[i], stride_bytes, 0.0f, df, &p, &sc);
         for (j = 0; j < n_models && rc == OSLAM_OK; j++) {
-            oslam_scene *sc = NULL;
-            /* the scene is prepared per model: its keys depend on the model's d_dist (ppf.cu:64-67) */
-            rc = oslam_scene_create(scene_xyz[i], scene_nrm[i], scene_n[i], stride_bytes, model_d_dists[j], df, &p, &sc);
-            if (rc == OSLAM_OK) {
-                int arc = oslam_align(models[j], sc, T_out + 16 * (i * n_models + j), NULL);
-                if (arc != OSLAM_OK && arc != OSLAM_E_NO_VOTES) rc = arc;
-            }
-            oslam_scene_destroy(sc);
+            int arc = oslam_align(models[j], sc, T_out + 16 * (i * n_models + j), NULL);
+            if (arc != OSLAM_OK && arc != OSLAM_E_NO_VOTES) rc = arc;
         }
+        oslam_scene_destroy(sc);
     }
     for (j = 0; j < n_models; j++) oslam_model_destroy(models[j]);
     free(models);
@@ -1296,6 +1296,33 @@ int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t
 done:
     free(tmp);
     free(tmi);
+    return rc;
+}
+
+int oslam_model_bucket_words(oslam_model *m, uint32_t key, int slice, uint32_t *words_out, size_t cap, size_t *count_out)
+{
+    int rc = OSLAM_OK;
+    oslamk_slot *tab = NULL;
+    uint32_t mask, slot, probe;
+    if (!m || !count_out || slice < 0 || slice >= m->table.n_slices) return fail(OSLAM_E_INVALID, "bad argument");
+    *count_out = 0;
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    tab = (oslamk_slot *)malloc(sizeof(oslamk_slot) * m->table.cap);
+    if (!tab) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    HIPCHK(hipMemcpy(tab, m->table.slots + (size_t)slice * m->table.cap, sizeof(oslamk_slot) * m->table.cap, hipMemcpyDeviceToHost));
+    mask = m->table.cap - 1;
+    slot = (key * 2654435761u) >> m->table.shift;
+    for (probe = 0; probe <= mask; probe++, slot = (slot + 1) & mask) {
+        if (tab[slot].key == key) {
+            size_t n = tab[slot].len < cap ? tab[slot].len : cap;
+            *count_out = tab[slot].len;
+            if (words_out && n) HIPCHK(hipMemcpy(words_out, m->ent.e4 + tab[slot].start, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+            break;
+        }
+        if (tab[slot].key == 0) break;
+    }
+done:
+    free(tab);
     return rc;
 }
 

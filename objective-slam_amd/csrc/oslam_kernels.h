@@ -98,6 +98,10 @@ int oslamk_reach_build(oslamk_table t, float d_dist, void *stream);
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
                       const float *tmg, oslamk_entries ent, void *stream);
 
+/* model build, pass 3: inside every bucket, order the entries so that the 32 lanes the LDS serves
+ * together carry evenly spaced theta_u (fewer bank conflicts of the vote atomics) */
+int oslamk_bucket_spread(oslamk_table t, oslamk_entries ent, void *stream);
+
 typedef struct oslamk_hit {
     uint32_t key, vy_bits, vz_bits, theta_t22;
 } oslamk_hit;

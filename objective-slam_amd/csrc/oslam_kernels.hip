@@ -210,6 +210,89 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
     }
 }
 
+/* pass 3: order inside every bucket.  A vote instruction adds 64 lanes' entries into
+ * acc[m_r][bin]; the LDS bank is the bin (rows are 32 words), and the bin is theta_v - theta_u, so
+ * within one instruction the banks are as spread as the theta_u of the 32 lanes the LDS serves
+ * together.  The fill pass leaves the entries in arrival order: 32 random angles on 30 banks
+ * collide 3-4 deep (7 LDS cycles per instruction instead of 4, tools/micro/lds_atomic_bench.hip).
+ * Here every segment of 4096 positions (16 chunks) of a bucket is sorted by theta_u and dealt out
+ * so that each such group of 32 (same chunk, same register j, same half of the wave) takes every
+ * G-th entry of the sorted order: evenly spaced angles, mostly distinct banks.  Votes commute, so
+ * the order inside a bucket is free (model.cu:95-171 sorts them anyway).  One workgroup per slot. */
+#define SPREAD_SEG 4096
+#define SPREAD_THREADS 256
+/* how many positions p' < n of a chunk image (position = 4*lane + j) come before position p in
+ * the dealing order (lane & 31, j, lane >> 5), for a chunk that holds n entries */
+__device__ __forceinline__ uint32_t spread_rank_in_chunk(uint32_t p, uint32_t n)
+{
+    const uint32_t lane = p >> 2, j = p & 3u, h = lane & 31u, g = lane >> 5;
+    uint32_t r = 0;
+    for (uint32_t h2 = 0; h2 < h; h2++) {
+        const uint32_t a0 = 4u * h2, a1 = 4u * (h2 + 32u);
+        r += (n > a0 ? (n - a0 < 4u ? n - a0 : 4u) : 0u) + (n > a1 ? (n - a1 < 4u ? n - a1 : 4u) : 0u);
+    }
+    for (uint32_t j2 = 0; j2 < 4; j2++)
+        for (uint32_t g2 = 0; g2 < 2; g2++) {
+            if (j2 > j || (j2 == j && g2 >= g)) continue;
+            r += (4u * (32u * g2 + h) + j2) < n;
+        }
+    return r;
+}
+__global__ __launch_bounds__(SPREAD_THREADS) void k_bucket_spread(oslamk_table t, oslamk_entries ent)
+{
+    __shared__ unsigned long long key[SPREAD_SEG];     /* theta_u << 32 | index in the segment */
+    __shared__ uint32_t s_e4[SPREAD_SEG];
+    __shared__ oslamk_uv s_uv[SPREAD_SEG];
+    __shared__ uint16_t s_mi[SPREAD_SEG];
+    const oslamk_slot sl = t.slots[blockIdx.x];
+    if (sl.key == 0 || sl.len < 2) return;
+    const int tid = threadIdx.x;
+    for (uint32_t seg = 0; seg < sl.len; seg += SPREAD_SEG) {
+        const uint32_t n = sl.len - seg < SPREAD_SEG ? sl.len - seg : SPREAD_SEG;
+        const size_t base = (size_t)sl.start + seg;
+        uint32_t P = 2;
+        while (P < n) P <<= 1;
+        for (uint32_t i = tid; i < P; i += SPREAD_THREADS) {
+            if (i < n) {
+                const uint32_t w = ent.e4[base + i];
+                s_e4[i] = w;
+                if (ent.uv) s_uv[i] = ent.uv[base + i];
+                s_mi[i] = ent.mi[base + i];
+                key[i] = ((unsigned long long)(w & 0x3fffffu) << 32) | i;
+            } else {
+                key[i] = ~0ull;
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t x = tid; x < P / 2; x += SPREAD_THREADS) {
+                    const uint32_t lo = ((x & ~(j - 1)) << 1) | (x & (j - 1)), hi = lo | j;
+                    const unsigned long long a = key[lo], b = key[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        /* position p of the segment takes the entry whose sorted rank is the number of positions
+         * dealt before p: (lane & 31) first, then chunk, then (j, half) */
+        const uint32_t n_full = n >> 8, n_last = n & 255u;
+        for (uint32_t p = tid; p < n; p += SPREAD_THREADS) {
+            const uint32_t c = p >> 8, q = p & 255u, h = (q >> 2) & 31u;
+            const uint32_t nc = c < n_full ? 256u : n_last;
+            uint32_t rank = 8u * h * n_full + spread_rank_in_chunk(4u * h, n_last);
+            rank += 8u * (c < n_full ? c : n_full);
+            rank += spread_rank_in_chunk(q, nc) - spread_rank_in_chunk(4u * h, nc);
+            const uint32_t src = (uint32_t)key[rank];
+            ent.e4[base + p] = s_e4[src];
+            if (ent.uv) ent.uv[base + p] = s_uv[src];
+            ent.mi[base + p] = s_mi[src];
+        }
+        __syncthreads();
+    }
+}
+
 /* --------------------------------------------------------------------------
  * voting
  * ------------------------------------------------------------------------*/
@@ -385,6 +468,9 @@ struct VoteRegs {
             rowb[j] = (w[j] >> 15) & 0x1ff80u;
             if (!FULL) rowb[j] = 4u * (uint32_t)lane + j < d.left ? rowb[j] : 4u * (ACC_TRASH + (uint32_t)lane);
         }
+        /* lanes that hold at least one entry of this chunk, and the accumulator's LDS address */
+        const unsigned long long live = FULL ? ~0ull : __ballot(4u * (uint32_t)lane < d.left);
+        const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_u32 *)acc;
         auto one_hit = [&](int i) {
             const uint32_t csm = readlane_u(csmv, i);
             uint32_t tm[4], addr[4];
@@ -405,9 +491,29 @@ struct VoteRegs {
                 if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
                     queue_edge_votes(a, hits, acc, tbl, sq, d.entry0, d.hbase + (uint32_t)i, d.left, forced, pos, addr, lane);
             }
+            if (FULL) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(acc) + addr[j]), 1u);
+                for (int j = 0; j < 4; j++)
+                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(acc) + addr[j]), 1u);
+            } else {
+                /* A chunk that is not full: the atomics are issued for the lanes that hold entries only
+                 * (EXEC narrowed around them), so the idle lanes cost no LDS cycles and cause no bank
+                 * conflicts; the one lane that holds fewer than four entries sends the rest to its
+                 * trash word.  Written in asm because the compiler has no way to say this; the
+                 * workgroup waits for these atomics (lgkmcnt) before it reads the accumulator. */
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\t"
+                             "s_mov_b64 exec, %1\n\t"
+                             "ds_add_u32 %2, %6\n\t"
+                             "ds_add_u32 %3, %6\n\t"
+                             "ds_add_u32 %4, %6\n\t"
+                             "ds_add_u32 %5, %6\n\t"
+                             "s_mov_b64 exec, %0"
+                             : "=&s"(saved)
+                             : "s"(live), "v"(acc_base + addr[0]), "v"(acc_base + addr[1]), "v"(acc_base + addr[2]),
+                               "v"(acc_base + addr[3]), "v"(1u)
+                             : "memory");
+            }
         };
         for (int i = d.i0; i < d.i1; i++) one_hit(i);
     }
@@ -822,6 +928,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 #ifdef VOTE_PROF
     const long long pt1 = clock64();
 #endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the atomics issued from asm (VoteRegs::vote_impl) */
     __syncthreads();
 #ifdef VOTE_PROF
     const long long pt2 = clock64();
@@ -1047,6 +1154,13 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
 {
     hipLaunchKernelGGL(k_model_fill, dim3((c.n + 255) / 256, c.n), dim3(256), 0, (hipStream_t)stream,
                        c, d_dist, inv_d_dist, t, tmg, ent);
+    return (int)hipGetLastError();
+}
+
+int oslamk_bucket_spread(oslamk_table t, oslamk_entries ent, void *stream)
+{
+    const size_t total = (size_t)t.n_slices * t.cap;
+    hipLaunchKernelGGL(k_bucket_spread, dim3((unsigned)total), dim3(SPREAD_THREADS), 0, (hipStream_t)stream, t, ent);
     return (int)hipGetLastError();
 }
 

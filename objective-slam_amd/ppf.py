@@ -79,6 +79,7 @@ _SIGNATURES = {
     "oslam_scene_keys": (_i, [_vp, _sz, _vp]),
     "oslam_model_keys": (_i, [_vp, _sz, _vp]),
     "oslam_model_bucket": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "oslam_model_bucket_words": (_i, [_vp, C.c_uint32, _i, _vp, _sz, C.POINTER(_sz)]),
     "oslam_vote_accumulator": (_i, [_vp, _vp, _sz, _vp]),
     "oslam_last_cells": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_set_stream": (_i, [_vp]),
@@ -293,6 +294,13 @@ class Model:
         n = C.c_size_t(0)
         _check(lib().oslam_model_bucket(self._h, int(key), _p(out), cap, C.byref(n)))
         return out[: min(n.value, cap)].copy(), n.value
+
+    def bucket_words(self, key, slice_index=0, cap=1 << 20):
+        """Stored entry words of `key`'s bucket in one slice, in storage order."""
+        out = np.zeros(cap, np.uint32)
+        n = C.c_size_t(0)
+        _check(lib().oslam_model_bucket_words(self._h, int(key), int(slice_index), _p(out), cap, C.byref(n)))
+        return out[: min(n.value, cap)].copy()
 
     def vote_accumulator(self, scene, ref_index):
         acc = np.zeros((self.n, 32), np.uint32)
