@@ -29,6 +29,12 @@
 #define VOTE_PIPE 2       /* steps whose loads are in flight ahead of the one being voted */
 #endif
 #define VOTE_THREADS 1024
+#ifndef VOTE_GRAINS
+#define VOTE_GRAINS 64       /* pieces the units of a workgroup are handed out in (16 waves) */
+#endif
+#ifndef VOTE_STEP_COST
+#define VOTE_STEP_COST 4     /* what a step (chunk load, set-up) costs, in units of one hit's votes: for the work split */
+#endif
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
 
 /* thresholds of pc_alpha_bin_table(); every vote workgroup copies them into LDS */
@@ -515,7 +521,9 @@ struct VoteRegs {
                              : "memory");
             }
         };
-        for (int i = d.i0; i < d.i1; i++) one_hit(i);
+        /* the step's range is in padded units (VOTE_STEP_COST after the hits): only the hits vote */
+        const int i_end = d.i1 < (int)d.R ? d.i1 : (int)d.R;
+        for (int i = d.i0; i < i_end; i++) one_hit(i);
     }
     __device__ __forceinline__ void vote(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
                                          const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
@@ -699,7 +707,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
  * Phase 1, all threads: one thread per run of the reference point probes the slice table (one
  * 16-byte slot load per probe); runs whose key is in the slice become items {bucket start, length,
  * first hit, hits}, compacted into this workgroup's scratch in HBM/L2.  A unit of work is one
- * (chunk of 256 entries, hit) pair, i.e. four LDS atomics per lane; the running sum of units is
+ * (chunk of 256 entries, hit) pair, i.e. four LDS atomics per lane, and a chunk costs
+ * VOTE_STEP_COST more units (after its hits) for its loads and set-up; the running sum of units is
  * kept for every 64th item.
  * Phase 2, no barriers: the units are split into 16 equal ranges, one per wave, so the waves
  * finish together whatever the bucket lengths are.  A wave finds its first item through the
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
     __shared__ unsigned long long s_wave64[VOTE_THREADS / WAVE];
-    __shared__ uint32_t s_g, s_lmax, s_base;
+    __shared__ uint32_t s_g, s_lmax, s_base, s_grain;
     __shared__ uint32_t s_tbl[32];
     __shared__ unsigned long long s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SlowQueue::CAP : 1];
 
@@ -731,6 +740,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 
     for (int c = tid; c < ACC_CELLS / 4; c += VOTE_THREADS) reinterpret_cast<uint4 *>(acc)[c] = make_uint4(0, 0, 0, 0);
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
+    if (tid == 0) s_grain = VOTE_THREADS / WAVE;           /* grains 0..15 are the waves' first ones */
 
     const oslamk_slot *tab = a.table.slots + (size_t)slice * a.table.cap;
     const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                 if (sv.x == rr.x) {
                     /* sv.w bit 31: the bucket holds an entry with the marker */
                     it = make_uint4(sv.y, sv.z | (sv.w & 0x80000000u), rr.y, R);
-                    units = (unsigned long long)((sv.z + 255u) >> 8) * R;
+                    units = (unsigned long long)((sv.z + 255u) >> 8) * (R + VOTE_STEP_COST);
                     my_votes += (unsigned long long)sv.z * R;
                     break;
                 }
@@ -807,9 +817,18 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     /* ---- phase 2: this wave's share of the units ---- */
     total = uni_u64(total);
     n_items = uni_u32(n_items);
-    const uint32_t wu = uni_u32((uint32_t)wid);
-    const unsigned long long lo = (total * wu) >> 4, hi = (total * (wu + 1u)) >> 4;
-    if (hi > lo) {
+    /* The units are cut into VOTE_GRAINS equal grains; a wave starts with grain `wid` and takes further
+     * ones from a counter in LDS as it finishes: equal shares by the unit count alone left the waves 21 %
+     * apart at the closing barrier (the cost of a unit varies with the chunk, the cache and the queue). */
+    const unsigned long long grain = (total + VOTE_GRAINS - 1) / VOTE_GRAINS;
+    for (uint32_t gi = uni_u32((uint32_t)wid); total != 0 && (unsigned long long)gi * grain < total;) {
+        const unsigned long long lo = (unsigned long long)gi * grain;
+        const unsigned long long hi = lo + grain < total ? lo + grain : total;
+        {
+            uint32_t nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&s_grain, 1u);
+            gi = uni_u32(readlane_u(nxt, 0));       /* the grain after this one */
+        }
 #ifdef VOTE_PROF
         const long long pt_a = clock64();
 #endif
@@ -834,7 +853,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         uint32_t kl;
         uint32_t o;
         {
-            const unsigned long long wu64 = (unsigned long long)(((win.y & 0x7fffffffu) + 255u) >> 8) * win.w;
+            const unsigned long long wu64 = win.w ? (unsigned long long)(((win.y & 0x7fffffffu) + 255u) >> 8) * (win.w + VOTE_STEP_COST) : 0ull;
             unsigned long long incl = wu64;
             for (int s2 = 1; s2 < WAVE; s2 <<= 1) {
                 const unsigned long long up = __shfl_up(incl, s2, WAVE);
@@ -858,7 +877,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             g_ln = lf & 0x7fffffffu;
             g_bf = (lf >> 31) != 0;
             g_h0 = readlane_u(win.z, (int)kl);
-            g_R = readlane_u(win.w, (int)kl);
+            g_R = readlane_u(win.w, (int)kl) + VOTE_STEP_COST;   /* hits + the units that stand for the step itself */
             g_C = (g_ln + 255u) >> 8;
         };
         open_item();
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                 d.left = g_ln - off;
                 d.entry0 = g_st + off;
                 d.hbase = g_h0;
-                d.R = g_R;
+                d.R = g_R - VOTE_STEP_COST;
                 d.bforced = g_bf;
                 d.i0 = (int)g_i0;
                 uint32_t nh = g_R - g_i0;
