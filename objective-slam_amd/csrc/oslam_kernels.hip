@@ -649,8 +649,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
         for (uint32_t i = tid; i < P; i += SORT_THREADS)
             buf[i] = i < n ? ((unsigned long long)src[i].x << 32) | i : ~0ull;
         __syncthreads();
+        /* Bitonic network.  A wave owns B = P/16 consecutive elements: passes whose partner distance j
+         * is below B stay inside the wave's block and need no workgroup barrier (a wave's LDS accesses
+         * are in program order), only the passes with j >= B do: 18 barriers at P = 8192 instead of 91,
+         * which is what this kernel's time was. */
+        const uint32_t B = P / (SORT_THREADS / WAVE);                 /* >= 4 */
         for (uint32_t k = 2; k <= P; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            uint32_t j = k >> 1;
+            if (j >= B) __syncthreads();                              /* other waves' blocks are read next */
+            for (; j >= B; j >>= 1) {
                 for (uint32_t t = tid; t < P / 2; t += SORT_THREADS) {
                     /* t-th compare-exchange of this pass: partner indices differ in bit j */
                     const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
@@ -660,7 +667,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
                 }
                 __syncthreads();
             }
+            for (; j > 0; j >>= 1) {
+                /* the same pass restricted to this wave's block: compare-exchanges wid*B/2 .. (wid+1)*B/2 */
+                for (uint32_t t = (uint32_t)wid * (B / 2) + (uint32_t)lane; t < ((uint32_t)wid + 1u) * (B / 2); t += WAVE) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const unsigned long long x = buf[lo], y = buf[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* the next pass reads what other lanes wrote */
+            }
         }
+        __syncthreads();
         for (uint32_t i = tid; i < n; i += SORT_THREADS) dst[i] = src[(uint32_t)buf[i]];
 
         /* run heads: thread t owns sorted positions [t*per, (t+1)*per) of the segment */
