@@ -21,6 +21,10 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstring>   /* rocPRIM calls memset without including it */
+
+#include <rocprim/block/block_radix_sort.hpp>
+
 #include "oslam_kernels.h"
 #include "ppf_core.h"
 
@@ -624,16 +628,19 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
  * average; streaming it once per run cuts the entry traffic 4.7x), and writes the run list the
  * vote kernel works from: runs[u] = {key, index of the run's first hit}; a run also ends at every
  * multiple of 64 hits, so a run piece is at most one hit per lane; runs[n_runs] = {0, n_hits}.
- * One workgroup per reference point: bitonic sort of (key << 32 | index) in LDS, then the records
- * are gathered into the second list.  A list longer than SORT_MAX is sorted in segments of
+ * One workgroup per reference point: radix sort of (key, index) in LDS, then the records are
+ * gathered into the second list.  A list longer than SORT_MAX is sorted in segments of
  * SORT_MAX hits (a key then has one run per segment it occurs in: its bucket is streamed once
  * per segment instead of once, everything else is unchanged). */
 #define SORT_MAX 16384
 #define SORT_THREADS 1024
+#define SORT_ITEMS (SORT_MAX / SORT_THREADS)
+typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_ITEMS, uint32_t> hit_block_sort;
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 {
-    __shared__ unsigned long long buf[SORT_MAX];
+    __shared__ typename hit_block_sort::storage_type s_sort;
     __shared__ uint32_t s_part[SORT_THREADS / WAVE];
+    __shared__ uint32_t s_last[SORT_THREADS];           /* the last key of every thread's 16 sorted positions */
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const uint32_t n_all = a.hit_count[ref_local];
     const uint4 *src_all = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
@@ -644,53 +651,35 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
         const uint32_t n = n_all - seg < SORT_MAX ? n_all - seg : SORT_MAX;
         const uint4 *src = src_all + seg;
         uint4 *dst = dst_all + seg;
-        uint32_t P = 64;
-        while (P < n) P <<= 1;
-        for (uint32_t i = tid; i < P; i += SORT_THREADS)
-            buf[i] = i < n ? ((unsigned long long)src[i].x << 32) | i : ~0ull;
-        __syncthreads();
-        /* Bitonic network.  A wave owns B = P/16 consecutive elements: passes whose partner distance j
-         * is below B stay inside the wave's block and need no workgroup barrier (a wave's LDS accesses
-         * are in program order), only the passes with j >= B do: 18 barriers at P = 8192 instead of 91,
-         * which is what this kernel's time was. */
-        const uint32_t B = P / (SORT_THREADS / WAVE);                 /* >= 4 */
-        for (uint32_t k = 2; k <= P; k <<= 1) {
-            uint32_t j = k >> 1;
-            if (j >= B) __syncthreads();                              /* other waves' blocks are read next */
-            for (; j >= B; j >>= 1) {
-                for (uint32_t t = tid; t < P / 2; t += SORT_THREADS) {
-                    /* t-th compare-exchange of this pass: partner indices differ in bit j */
-                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                    const unsigned long long x = buf[lo], y = buf[hi];
-                    const bool up = (lo & k) == 0;
-                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
-                }
-                __syncthreads();
-            }
-            for (; j > 0; j >>= 1) {
-                /* the same pass restricted to this wave's block: compare-exchanges wid*B/2 .. (wid+1)*B/2 */
-                for (uint32_t t = (uint32_t)wid * (B / 2) + (uint32_t)lane; t < ((uint32_t)wid + 1u) * (B / 2); t += WAVE) {
-                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                    const unsigned long long x = buf[lo], y = buf[hi];
-                    const bool up = (lo & k) == 0;
-                    if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   /* the next pass reads what other lanes wrote */
-            }
+        /* An LDS radix sort (rocPRIM's block primitive) of (key, index): thread t brings the hits
+         * 16t .. 16t+15 and ends up with the sorted positions 16t .. 16t+15 in registers.  Places past
+         * the end carry the largest key; the sort is stable and they come last in the input order, so
+         * they also come last among equal keys and the first n sorted positions are the hits. */
+        const uint32_t i0 = (uint32_t)tid * SORT_ITEMS;
+        uint32_t key[SORT_ITEMS], idx[SORT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
+            const uint32_t i = i0 + k;
+            key[k] = i < n ? src[i].x : 0xffffffffu;
+            idx[k] = i;
         }
+        hit_block_sort().sort(key, idx, s_sort);
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++)
+            if (i0 + k < n) dst[i0 + k] = src[idx[k]];
+        s_last[tid] = key[SORT_ITEMS - 1];
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += SORT_THREADS) dst[i] = src[(uint32_t)buf[i]];
-
-        /* run heads: thread t owns sorted positions [t*per, (t+1)*per) of the segment */
-        const uint32_t per = SORT_MAX / SORT_THREADS, i0 = (uint32_t)tid * per;
         uint32_t heads = 0, cnt = 0;
-        for (uint32_t k = 0; k < per; k++) {
+        uint32_t prev = tid ? s_last[tid - 1] : 0u;
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++) {
             const uint32_t i = i0 + k;
             if (i < n) {
-                const bool head = (i & (WAVE - 1)) == 0 || (uint32_t)(buf[i] >> 32) != (uint32_t)(buf[i - 1] >> 32);
+                const bool head = (i & (WAVE - 1)) == 0 || key[k] != prev;
                 heads |= (uint32_t)head << k;
                 cnt += head;
             }
+            prev = key[k];
         }
         uint32_t incl = cnt;
         for (int o = 1; o < WAVE; o <<= 1) {
@@ -705,10 +694,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
             if (w < wid) pos += v;
             total += v;
         }
-        for (uint32_t k = 0; k < per; k++)
-            if ((heads >> k) & 1u) runs[pos++] = make_uint2((uint32_t)(buf[i0 + k] >> 32), seg + i0 + k);
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; k++)
+            if ((heads >> k) & 1u) runs[pos++] = make_uint2(key[k], seg + i0 + k);
         n_runs += total;
-        __syncthreads();                /* buf and s_part are reused by the next segment */
+        __syncthreads();                /* the LDS arrays are reused by the next segment */
     }
     if (tid == 0) {
         runs[n_runs] = make_uint2(0u, n_all);
