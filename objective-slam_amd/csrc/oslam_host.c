@@ -717,7 +717,7 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
 
 /* Scratch for the hit lists of one batch of reference points: one pool per device, shared by all
  * models (it is only live inside an align call; like the reference, calls on one device are not
- * re-entrant).  Up to OSLAM_SCRATCH_GIB GiB (default: a quarter of the free device memory, at least 16), at least one reference point's worth. */
+ * re-entrant).  Up to OSLAM_SCRATCH_GIB GiB (default 32, or a quarter of the free device memory if that is less), at least one reference point's worth. */
 #define MAX_DEVICES 64
 typedef struct {
     oslamk_hit *hits;
@@ -744,9 +744,12 @@ static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratc
     if (env && atoi(env) > 0) {
         cap = (size_t)atoi(env) << 30;
     } else {
-        /* default: a quarter of what is free now (72 GB of an idle MI355X), at least 16 GiB */
+        /* default: 32 GiB, or a quarter of what is free if that is less.  Mapping the pool costs about
+         * 40 ms per GiB once per process; the batches it allows cost 107 / 101 / 98 / 97 ms per
+         * 5k x 100k registration at 8 / 16 / 32 / 64 GiB (fewer, fuller launches) */
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (fr + p->hits_bytes) / 4 > cap) cap = (fr + p->hits_bytes) / 4;
+        cap = (size_t)32 << 30;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (fr + p->hits_bytes) / 4 < cap) cap = (fr + p->hits_bytes) / 4;
     }
     if (want > cap) want = cap;
     if (want < per_ref) want = per_ref;
