@@ -445,7 +445,8 @@ struct VoteRegs {
     __device__ __forceinline__ static void queue_edge_votes(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
                                                             const uint32_t *tbl, SlowQueue &sq, uint32_t entry0,
                                                             uint32_t hit, uint32_t left, bool forced,
-                                                            const uint32_t (&pos)[4], uint32_t (&addr)[4], int lane)
+                                                            const uint32_t (&pos)[4], uint32_t (&addr)[4], int lane,
+                                                            uint32_t trash_addr)
     {
         uint32_t e = 4u * (uint32_t)lane;
         asm volatile("" : "+v"(e));      /* keeps the compares below out of the vote loop's preamble */
@@ -455,7 +456,7 @@ struct VoteRegs {
             if (nm) {
                 if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, hits, acc, tbl, lane);
                 sq.push(nm, lane, entry0 + e + j, hit);
-                if ((nm >> lane) & 1ull) addr[j] = 4u * (ACC_TRASH + (uint32_t)lane);
+                if ((nm >> lane) & 1ull) addr[j] = trash_addr;
             }
         }
     }
@@ -470,17 +471,19 @@ struct VoteRegs {
     {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t24(th);
+        const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_u32 *)acc;        /* the accumulator's LDS address */
         uint32_t wa[4], rowb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             wa[j] = w[j] << 2;
             /* byte offset of the entry's accumulator row, or of the lane's trash word */
             rowb[j] = (w[j] >> 15) & 0x1ff80u;
-            if (!FULL) rowb[j] = 4u * (uint32_t)lane + j < d.left ? rowb[j] : 4u * (ACC_TRASH + (uint32_t)lane);
+            /* the partial variant issues its atomics from asm with absolute LDS addresses */
+            if (!FULL) rowb[j] = acc_base + (4u * (uint32_t)lane + j < d.left ? rowb[j] : 4u * (ACC_TRASH + (uint32_t)lane));
         }
-        /* lanes that hold at least one entry of this chunk, and the accumulator's LDS address */
+        const uint32_t trash_addr = (FULL ? 0u : acc_base) + 4u * (ACC_TRASH + (uint32_t)lane);
+        /* lanes that hold at least one entry of this chunk */
         const unsigned long long live = FULL ? ~0ull : __ballot(4u * (uint32_t)lane < d.left);
-        const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_u32 *)acc;
         auto one_hit = [&](int i) {
             const uint32_t csm = readlane_u(csmv, i);
             uint32_t tm[4], addr[4];
@@ -499,7 +502,7 @@ struct VoteRegs {
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
                 const bool forced = FORCED && ((fmask >> i) & 1ull);
                 if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
-                    queue_edge_votes(a, hits, acc, tbl, sq, d.entry0, d.hbase + (uint32_t)i, d.left, forced, pos, addr, lane);
+                    queue_edge_votes(a, hits, acc, tbl, sq, d.entry0, d.hbase + (uint32_t)i, d.left, forced, pos, addr, lane, trash_addr);
             }
             if (FULL) {
 #pragma unroll
@@ -520,8 +523,7 @@ struct VoteRegs {
                              "ds_add_u32 %5, %6\n\t"
                              "s_mov_b64 exec, %0"
                              : "=&s"(saved)
-                             : "s"(live), "v"(acc_base + addr[0]), "v"(acc_base + addr[1]), "v"(acc_base + addr[2]),
-                               "v"(acc_base + addr[3]), "v"(1u)
+                             : "s"(live), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(1u)
                              : "memory");
             }
         };
