@@ -170,6 +170,15 @@ typedef struct oslam_camera {
 int oslam_depth_to_cloud(const void *depth, int depth_is_u16, int width, int height, const oslam_camera *cam,
                          int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out);
 
+/* The streaming chain in one call: depth image -> points + normals -> voxel grid (leaf > 0; 0 skips
+ * it) -> scene, with the full-resolution cloud staying in HBM between the stages (only the image goes
+ * up and the voxel-gridded cloud comes back for the host's reference frames).  Equivalent to
+ * oslam_depth_to_cloud + oslam_voxel_grid + oslam_scene_create with the same arguments.  *n_points_out
+ * (may be NULL) = points of the scene.  OSLAM_E_INVALID if fewer than 2 points remain. */
+int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int height, const oslam_camera *cam,
+                           float leaf, float d_dist, unsigned ref_point_downsample_factor,
+                           const oslam_params *params, oslam_scene **out, size_t *n_points_out);
+
 /* PLY clouds with normals (host only): pcl::io::loadPLYFile<pcl::PointNormal>
  * (src/alignment.cpp:212,241) / pcl::PLYWriter (pcl/voxel_grid/voxel_grid.cpp:27-29).
  * Reads ascii and binary_little_endian; needs x y z and nx ny nz (or normal_x normal_y

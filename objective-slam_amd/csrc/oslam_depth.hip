@@ -94,6 +94,21 @@ __global__ void k_depth_compact(const float *in6, const uint32_t *flags, const u
     for (int a = 0; a < 6; a++) o[a] = s[a];
 }
 
+/* [n][6] records -> structure of arrays (what the voxel-grid and key kernels read) */
+__global__ void k_aos6_to_soa(const float *in6, size_t n, float *soa)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int a = 0; a < 6; a++) soa[(size_t)a * n + i] = in6[6 * i + a];
+}
+
+extern "C" int oslamk_aos6_to_soa(const float *d_in6, size_t n, float *d_soa, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_aos6_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in6, n, d_soa);
+    return (int)hipGetLastError();
+}
+
 #define DCHK(call)                   \
     do {                             \
         hipError_t e_ = (call);      \

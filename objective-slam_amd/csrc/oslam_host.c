@@ -705,6 +705,74 @@ done:
     return OSLAM_OK;
 }
 
+int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int height, const oslam_camera *cam,
+                           float leaf, float d_dist, unsigned df, const oslam_params *params, oslam_scene **out,
+                           size_t *n_points_out)
+{
+    int rc = OSLAM_OK, k, devsel;
+    oslam_params p;
+    void *d_img = NULL;
+    float *d_pts6 = NULL, *d_soa = NULL, *d_vox6 = NULL, *h6 = NULL, *h_xyz = NULL, *h_nrm = NULL;
+    const float *d_final;
+    uint32_t np = 0, nv = 0;
+    size_t i, n_pix, px_bytes, n_final;
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (n_points_out) *n_points_out = 0;
+    if (!depth || !cam || width < 3 || height < 3 || width > 16384 || height > 16384 || !(cam->fx > 0.0f) ||
+        !(cam->fy > 0.0f) || !(cam->depth_scale > 0.0f) || !(cam->z_max >= cam->z_min) || !(cam->z_min > 0.0f) ||
+        !(cam->max_jump >= 0.0f) || !(leaf >= 0.0f))
+        return fail(OSLAM_E_INVALID, "bad depth image arguments");
+    if (params) p = *params; else oslam_params_default(&p);
+    n_pix = (size_t)width * (size_t)height;
+    px_bytes = depth_is_u16 ? 2 : 4;
+    rc = pick_device(p.dev, &devsel);
+    if (rc != OSLAM_OK) return rc;
+    HIPCHK(hipMalloc(&d_img, n_pix * px_bytes));
+    HIPCHK(hipMalloc((void **)&d_pts6, sizeof(float) * 6 * n_pix));
+    HIPCHK(hipMemcpyAsync(d_img, depth, n_pix * px_bytes, hipMemcpyHostToDevice, (hipStream_t)g_stream));
+    k = oslamk_depth_to_cloud(d_img, depth_is_u16 != 0, width, height, cam->fx, cam->fy, cam->cx, cam->cy, cam->depth_scale,
+                              cam->z_min, cam->z_max, cam->max_jump, d_pts6, &np, g_stream);
+    if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
+    d_final = d_pts6;
+    n_final = np;
+    if (leaf > 0.0f && np > 0) {
+        oslamk_cloud c;
+        HIPCHK(hipMalloc((void **)&d_soa, sizeof(float) * 6 * (size_t)np));
+        HIPCHK(hipMalloc((void **)&d_vox6, sizeof(float) * 6 * (size_t)np));
+        KCHK(oslamk_aos6_to_soa(d_pts6, np, d_soa, g_stream));
+        c.px = d_soa; c.py = d_soa + np; c.pz = d_soa + 2 * (size_t)np;
+        c.nx = d_soa + 3 * (size_t)np; c.ny = d_soa + 4 * (size_t)np; c.nz = d_soa + 5 * (size_t)np;
+        c.n = (int)np;
+        k = oslamk_voxel_grid(c, leaf, d_vox6, &nv, g_stream);
+        if (k == -1) { rc = fail(OSLAM_E_LIMIT, "leaf size too small for the cloud extent (voxel count overflows int32)"); goto done; }
+        if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
+        d_final = d_vox6;
+        n_final = nv;
+    }
+    if (n_final < 2) { rc = fail(OSLAM_E_INVALID, "the depth image leaves fewer than 2 scene points"); goto done; }
+    h6 = (float *)malloc(sizeof(float) * 6 * n_final);
+    h_xyz = (float *)malloc(sizeof(float) * 3 * n_final);
+    h_nrm = (float *)malloc(sizeof(float) * 3 * n_final);
+    if (!h6 || !h_xyz || !h_nrm) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    HIPCHK(hipMemcpy(h6, d_final, sizeof(float) * 6 * n_final, hipMemcpyDeviceToHost));
+    for (i = 0; i < n_final; i++) {
+        memcpy(h_xyz + 3 * i, h6 + 6 * i, 3 * sizeof(float));
+        memcpy(h_nrm + 3 * i, h6 + 6 * i + 3, 3 * sizeof(float));
+    }
+    rc = oslam_scene_create(h_xyz, h_nrm, n_final, 12, d_dist, df, &p, out);
+    if (rc == OSLAM_OK && n_points_out) *n_points_out = n_final;
+done:
+    free(h6);
+    free(h_xyz);
+    free(h_nrm);
+    if (d_img) (void)hipFree(d_img);
+    if (d_pts6) (void)hipFree(d_pts6);
+    if (d_soa) (void)hipFree(d_soa);
+    if (d_vox6) (void)hipFree(d_vox6);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------ */
 static int check_pair(const oslam_model *m, const oslam_scene *s)
 {

@@ -159,6 +159,9 @@ int oslamk_depth_to_cloud(const void *d_img, int is_u16, int w, int h, float fx,
                           float scale, float z_min, float z_max, float max_jump, float *d_out6, uint32_t *n_out,
                           void *stream);
 
+/* device [n][6] (x y z nx ny nz) -> device structure of arrays [6][n] */
+int oslamk_aos6_to_soa(const float *d_in6, size_t n, float *d_soa, void *stream);
+
 /* clustering scores of n poses (device arrays).  shash[j] = cell hash of the j-th pose in
  * (hash, pose index) order; sq/st/sw = quaternions [n][4], translations [n][3], weighted votes [n]
  * in that order; trans/quat/cell in pose order.  The translation-averaging variant stays on the host. */

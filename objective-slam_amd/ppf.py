@@ -69,6 +69,7 @@ _SIGNATURES = {
     "oslam_ply_write": (_i, [C.c_char_p, _vp, _vp, _sz, _i]),
     "oslam_free": (None, [_vp]),
     "oslam_depth_to_cloud": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "oslam_scene_from_depth": (_i, [_vp, _i, _i, _i, _vp, _f, _f, _u, C.POINTER(Params), C.POINTER(_vp), C.POINTER(_sz)]),
     "oslam_voxel_grid": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _vp, _sz, C.POINTER(_sz)]),
     "oslam_build_T_g": (None, [_vp, _vp, _vp]),
     "oslam_sort_cells": (None, [_vp, _sz]),
@@ -161,6 +162,26 @@ class Scene:
         self.df = int(ref_point_downsample_factor)
         self.n = n
         _check(lib().oslam_scene_create(xyz, nrm, n, stride, self.d_dist, self.df, C.byref(self.params), C.byref(self._h)))
+
+    @classmethod
+    def from_depth(cls, depth, fx, fy, cx, cy, leaf, d_dist=0.0, ref_point_downsample_factor=1, depth_scale=0.001,
+                   z_min=0.1, z_max=10.0, max_jump=0.05, params=None):
+        """Depth frame -> points + normals -> voxel grid -> Scene in one call, the full-resolution cloud
+        staying in HBM (oslam_scene_from_depth)."""
+        d = np.ascontiguousarray(depth)
+        if d.dtype not in (np.uint16, np.float32) or d.ndim != 2:
+            raise ValueError("depth must be a 2-D uint16 or float32 image")
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(0)
+        self.params = params if params is not None else default_params()
+        self.d_dist, self.df = float(d_dist), int(ref_point_downsample_factor)
+        cam = Camera(fx, fy, cx, cy, depth_scale, z_min, z_max, max_jump)
+        n = C.c_size_t(0)
+        _check(lib().oslam_scene_from_depth(_p(d), int(d.dtype == np.uint16), d.shape[1], d.shape[0], C.byref(cam),
+                                            float(leaf), self.d_dist, self.df, C.byref(self.params), C.byref(self._h),
+                                            C.byref(n)))
+        self.n = n.value
+        return self
 
     def numPoints(self):
         return self.n

@@ -532,9 +532,19 @@ def test_depth_frame_to_pose(ppf, built_lib, synth):
     assert len(sp) > 50000
     sp, sn = ppf.voxel_grid(sp, sn, leaf=d)
     mg, mgn = ppf.voxel_grid(mp, mn, leaf=d)
-    Tm = ppf.Model(mg, mgn, d_dist=d).ppf_lookup(ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=2))
+    mo = ppf.Model(mg, mgn, d_dist=d)
+    Tm = mo.ppf_lookup(ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=2)).copy()
+    cells_a, _ = mo.last_cells()
     dt, dr = ppf.ht_dist(Tm, T)
     assert dr < np.deg2rad(12) and dt < 0.1 * diam, (np.degrees(dr), dt / diam)
+    # the same chain in one call, the full-resolution cloud staying in HBM: the same scene, cell for cell
+    sc = ppf.Scene.from_depth(img, 525.0, 525.0, 319.5, 239.5, leaf=d, d_dist=d, ref_point_downsample_factor=2,
+                              z_min=0.5, z_max=12.0, max_jump=0.08)
+    assert sc.numPoints() == len(sp)
+    Tc = mo.ppf_lookup(sc)
+    assert np.array_equal(Tc, Tm) and cells_equal(mo.last_cells()[0], cells_a)
+    with pytest.raises(ppf.OslamError):
+        ppf.Scene.from_depth(np.zeros((480, 640), np.uint16), 525.0, 525.0, 319.5, 239.5, leaf=d)   # no valid pixel
 
 
 @pytest.fixture

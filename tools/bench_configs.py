@@ -99,27 +99,26 @@ def cfg5(n_models=4, frames=8):
     leaf = min(dd)                                                 # one scene_leaf_size for all models (alignment.cpp:265-271)
     def one(img):
         t0 = time.perf_counter()
-        sp, sn = ppf.depth_to_cloud(img, 525.0, 525.0, 319.5, 239.5, z_min=0.5, z_max=12.0, max_jump=0.08)
+        # depth -> points + normals -> voxel grid -> scene in one call (d_dist 0: a scene for every model)
+        sc = ppf.Scene.from_depth(img, 525.0, 525.0, 319.5, 239.5, leaf=leaf, d_dist=0.0, ref_point_downsample_factor=2,
+                                  z_min=0.5, z_max=12.0, max_jump=0.08)
         t1 = time.perf_counter()
-        g = ppf.voxel_grid(sp, sn, leaf=leaf)
-        t_vox = time.perf_counter() - t1
-        ta = time.perf_counter()
-        sc = ppf.Scene(g[0], g[1], d_dist=0.0, ref_point_downsample_factor=2)   # d_dist 0: a scene for every model
         out, votes = [], 0
         for mo in models:
             out.append(mo.ppf_lookup(sc, allow_no_votes=True).copy())
             votes += mo.stats["num_votes"]
+        n_scene = sc.numPoints()
         sc.close()
-        t_al = time.perf_counter() - ta
-        return out, t1 - t0, t_vox, time.perf_counter() - t0, len(sp), len(g[0]), t_al, votes
+        t2 = time.perf_counter()
+        return out, t1 - t0, 0.0, t2 - t0, 0, n_scene, t2 - t1, votes
     one(imgs[0])
     t = time.perf_counter(); res = [one(im) for im in imgs]; el = time.perf_counter() - t
     ok = sum(found_at_reference_criterion(r[0][j], truths[f][j], clouds[j][0]) for f, r in enumerate(res) for j in range(2))
-    return {"config": "cfg5: 640x480 depth frames vs a %d-model database (host hand-offs between the stages)" % n_models,
+    return {"config": "cfg5: 640x480 depth frames vs a %d-model database (oslam_scene_from_depth, then one align per model)" % n_models,
             "frames": frames, "frames_per_s": frames / el, "ms_per_frame": 1e3 * el / frames,
-            "ms_depth_to_cloud": 1e3 * np.mean([r[1] for r in res]), "ms_voxel_grid": 1e3 * np.mean([r[2] for r in res]),
+            "ms_depth_to_scene": 1e3 * np.mean([r[1] for r in res]),
             "ms_registration_all_models": 1e3 * np.mean([r[6] for r in res]), "votes_per_frame": int(np.mean([r[7] for r in res])),
-            "points_per_frame": int(np.mean([r[4] for r in res])), "scene_points_after_voxel_grid": int(np.mean([r[5] for r in res])),
+            "scene_points_after_voxel_grid": int(np.mean([r[5] for r in res])),
             "objects_found": "%d of %d" % (ok, 2 * frames)}
 
 
