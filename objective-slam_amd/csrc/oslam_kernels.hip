@@ -637,12 +637,75 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 #define SORT_MAX 16384
 #define SORT_THREADS 1024
 #define SORT_ITEMS (SORT_MAX / SORT_THREADS)
+#define SORT_SMALL_ITEMS 2                      /* lists of up to 2048 hits (small scenes) take a 2-per-thread sort */
 typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_ITEMS, uint32_t> hit_block_sort;
+typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_SMALL_ITEMS, uint32_t> hit_block_sort_small;
+
+/* One segment of n <= ITEMS * 1024 hits: sort, gather, run heads.  Returns the segment's run count (the
+ * same value in every thread). */
+template <int ITEMS, class SORT>
+__device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_sort, uint32_t *s_part, uint32_t *s_last,
+                                                 const uint4 *src, uint4 *dst, uint2 *runs, uint32_t n, uint32_t seg,
+                                                 uint32_t n_runs, int tid, int lane, int wid)
+{
+    /* An LDS radix sort (rocPRIM's block primitive) of (key, index): thread t brings the hits
+     * ITEMS*t .. ITEMS*t+ITEMS-1 and ends up with the same sorted positions in registers.  Places past
+     * the end carry the largest key; the sort is stable and they come last in the input order, so
+     * they also come last among equal keys and the first n sorted positions are the hits. */
+    const uint32_t i0 = (uint32_t)tid * ITEMS;
+    uint32_t key[ITEMS], idx[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = i0 + k;
+        key[k] = i < n ? src[i].x : 0xffffffffu;
+        idx[k] = i;
+    }
+    SORT().sort(key, idx, s_sort);
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+        if (i0 + k < n) dst[i0 + k] = src[idx[k]];
+    s_last[tid] = key[ITEMS - 1];
+    __syncthreads();
+    uint32_t heads = 0, cnt = 0;
+    uint32_t prev = tid ? s_last[tid - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const uint32_t i = i0 + k;
+        if (i < n) {
+            const bool head = (i & (WAVE - 1)) == 0 || key[k] != prev;
+            heads |= (uint32_t)head << k;
+            cnt += head;
+        }
+        prev = key[k];
+    }
+    uint32_t incl = cnt;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += up;
+    }
+    if (lane == WAVE - 1) s_part[wid] = incl;
+    __syncthreads();
+    uint32_t pos = n_runs + incl - cnt, total = 0;
+    for (int w = 0; w < SORT_THREADS / WAVE; w++) {
+        const uint32_t v = s_part[w];
+        if (w < wid) pos += v;
+        total += v;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+        if ((heads >> k) & 1u) runs[pos++] = make_uint2(key[k], seg + i0 + k);
+    __syncthreads();                    /* the LDS arrays are reused by the next segment */
+    return total;
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 {
-    __shared__ typename hit_block_sort::storage_type s_sort;
+    __shared__ union {
+        typename hit_block_sort::storage_type big;
+        typename hit_block_sort_small::storage_type small;
+    } s_sort;
     __shared__ uint32_t s_part[SORT_THREADS / WAVE];
-    __shared__ uint32_t s_last[SORT_THREADS];           /* the last key of every thread's 16 sorted positions */
+    __shared__ uint32_t s_last[SORT_THREADS];           /* the last key of every thread's sorted positions */
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const uint32_t n_all = a.hit_count[ref_local];
     const uint4 *src_all = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
@@ -651,56 +714,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
     uint32_t n_runs = 0;                /* the same value in every thread */
     for (uint32_t seg = 0; seg < n_all; seg += SORT_MAX) {
         const uint32_t n = n_all - seg < SORT_MAX ? n_all - seg : SORT_MAX;
-        const uint4 *src = src_all + seg;
-        uint4 *dst = dst_all + seg;
-        /* An LDS radix sort (rocPRIM's block primitive) of (key, index): thread t brings the hits
-         * 16t .. 16t+15 and ends up with the sorted positions 16t .. 16t+15 in registers.  Places past
-         * the end carry the largest key; the sort is stable and they come last in the input order, so
-         * they also come last among equal keys and the first n sorted positions are the hits. */
-        const uint32_t i0 = (uint32_t)tid * SORT_ITEMS;
-        uint32_t key[SORT_ITEMS], idx[SORT_ITEMS];
-#pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++) {
-            const uint32_t i = i0 + k;
-            key[k] = i < n ? src[i].x : 0xffffffffu;
-            idx[k] = i;
-        }
-        hit_block_sort().sort(key, idx, s_sort);
-#pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++)
-            if (i0 + k < n) dst[i0 + k] = src[idx[k]];
-        s_last[tid] = key[SORT_ITEMS - 1];
-        __syncthreads();
-        uint32_t heads = 0, cnt = 0;
-        uint32_t prev = tid ? s_last[tid - 1] : 0u;
-#pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++) {
-            const uint32_t i = i0 + k;
-            if (i < n) {
-                const bool head = (i & (WAVE - 1)) == 0 || key[k] != prev;
-                heads |= (uint32_t)head << k;
-                cnt += head;
-            }
-            prev = key[k];
-        }
-        uint32_t incl = cnt;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += up;
-        }
-        if (lane == WAVE - 1) s_part[wid] = incl;
-        __syncthreads();
-        uint32_t pos = n_runs + incl - cnt, total = 0;
-        for (int w = 0; w < SORT_THREADS / WAVE; w++) {
-            const uint32_t v = s_part[w];
-            if (w < wid) pos += v;
-            total += v;
-        }
-#pragma unroll
-        for (int k = 0; k < SORT_ITEMS; k++)
-            if ((heads >> k) & 1u) runs[pos++] = make_uint2(key[k], seg + i0 + k);
-        n_runs += total;
-        __syncthreads();                /* the LDS arrays are reused by the next segment */
+        if (n <= SORT_SMALL_ITEMS * SORT_THREADS)
+            n_runs += sort_segment<SORT_SMALL_ITEMS, hit_block_sort_small>(s_sort.small, s_part, s_last, src_all + seg,
+                                                                           dst_all + seg, runs, n, seg, n_runs, tid, lane, wid);
+        else
+            n_runs += sort_segment<SORT_ITEMS, hit_block_sort>(s_sort.big, s_part, s_last, src_all + seg, dst_all + seg,
+                                                               runs, n, seg, n_runs, tid, lane, wid);
     }
     if (tid == 0) {
         runs[n_runs] = make_uint2(0u, n_all);
