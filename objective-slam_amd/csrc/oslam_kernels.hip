@@ -1106,41 +1106,52 @@ __global__ __launch_bounds__(64) void k_cluster_scores(int n, const float *trans
     const float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
     const int cx = cell[3 * i], cy = cell[3 * i + 1], cz = cell[3 * i + 2];
     float votes = 1;                                             /* kernel.cu:722 */
-    for (int dx = -1; dx < 2; dx++)
-        for (int dy = -1; dy < 2; dy++)
-            for (int dz = -1; dz < 2; dz++) {
-                if (dx == 0 && dy == 0 && dz == 0) continue;     /* kernel.cu:684-689 */
-                const uint32_t h = fnv_cell3(cx + dx, cy + dy, cz + dz);
-                if (h == 0) continue;
-                int lo = 0, hi = n;
-                while (lo < hi) {
-                    const int mid = lo + (hi - lo) / 2;
-                    if (shash[mid] < h) lo = mid + 1; else hi = mid;
-                }
-                for (int base = lo; base < n; base += WAVE) {
-                    const int j = base + lane;
-                    bool ok = false;
-                    float w = 0.0f;
-                    const bool in_cell = j < n && shash[j] == h;
-                    if (in_cell) {
-                        const float4 qo = sq[j];
-                        const float qd = fabsf(8 * (1 - (q0 * qo.x + q1 * qo.y + q2 * qo.z + q3 * qo.w)));
-                        ok = qd < rot_thresh_sq;
-                        if (ok && !use_l1) {
-                            const float ex = tx - st[3 * j], ey = ty - st[3 * j + 1], ez = tz - st[3 * j + 2];
-                            ok = pm_sqrtf(ex * ex + ey * ey + ez * ez) < d_dist;
-                        }
-                        w = sw[j];
-                    }
-                    unsigned long long m = __ballot(ok);
-                    while (m) {                                  /* ascending j: the reference's order */
-                        const int b = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        votes += readlane_f(w, b);
-                    }
-                    if (__ballot(in_cell) != ~0ull) break;       /* the cell's run ended in this step */
-                }
+    /* the 26 neighbour cells in the reference's (dx, dy, dz) order = ascending c; lane c finds the start of
+     * cell c's poses in the sorted list (26 binary searches side by side instead of one after the other:
+     * with 10^6 poses the dependent loads of the searches were most of this kernel's time) */
+    uint32_t my_h = 0;
+    int my_lo = n;
+    if (lane < 27 && lane != 13) {
+        const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
+        my_h = fnv_cell3(cx + dx, cy + dy, cz + dz);
+        if (my_h != 0) {                                          /* a hash of 0 is never searched (kernel.cu:727) */
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = lo + (hi - lo) / 2;
+                if (shash[mid] < my_h) lo = mid + 1; else hi = mid;
             }
+            my_lo = lo;
+        }
+    }
+    for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;                                   /* kernel.cu:684-689 */
+        const uint32_t h = readlane_u(my_h, c);
+        if (h == 0) continue;
+        const int lo = (int)readlane_u((uint32_t)my_lo, c);
+        for (int base = lo; base < n; base += WAVE) {
+            const int j = base + lane;
+            bool ok = false;
+            float w = 0.0f;
+            const bool in_cell = j < n && shash[j] == h;
+            if (in_cell) {
+                const float4 qo = sq[j];
+                const float qd = fabsf(8 * (1 - (q0 * qo.x + q1 * qo.y + q2 * qo.z + q3 * qo.w)));
+                ok = qd < rot_thresh_sq;
+                if (ok && !use_l1) {
+                    const float ex = tx - st[3 * j], ey = ty - st[3 * j + 1], ez = tz - st[3 * j + 2];
+                    ok = pm_sqrtf(ex * ex + ey * ey + ez * ez) < d_dist;
+                }
+                w = sw[j];
+            }
+            unsigned long long m = __ballot(ok);
+            while (m) {                                          /* ascending j: the reference's order */
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                votes += readlane_f(w, b);
+            }
+            if (__ballot(in_cell) != ~0ull) break;               /* the cell's run ended in this step */
+        }
+    }
     if (lane == 0) score[i] = votes;
 }
 
