@@ -158,3 +158,25 @@ def test_model_file_rejections_need_no_gpu(built_lib, ppf, tmp_path):
     with pytest.raises(ppf.OslamError) as e:
         ppf.Model.load(f)
     assert e.value.code == ppf.OSLAM_E_INVALID and "layout version" in str(e.value)
+
+
+def test_depth_entry_points_check_arguments_first(built_lib, ppf):
+    """oslam_depth_to_cloud / oslam_scene_from_depth validate the image and the camera before they look
+    for a device; with good arguments and no GPU they report OSLAM_E_DEVICE (no CPU fallback)."""
+    import torch
+    img = np.full((8, 8), 1000, np.uint16)
+    for bad in (dict(fx=0.0), dict(depth_scale=0.0), dict(z_min=0.0), dict(z_min=2.0, z_max=1.0), dict(max_jump=-1.0)):
+        kw = dict(fx=10.0, fy=10.0, cx=4.0, cy=4.0, depth_scale=0.001, z_min=0.1, z_max=10.0, max_jump=0.05)
+        kw.update(bad)
+        with pytest.raises(ppf.OslamError) as e:
+            ppf.depth_to_cloud(img, **kw)
+        assert e.value.code == ppf.OSLAM_E_INVALID
+    with pytest.raises(ppf.OslamError) as e:
+        ppf.Scene.from_depth(img[:2], 10.0, 10.0, 4.0, 4.0, leaf=0.1)         # fewer than 3 rows
+    assert e.value.code == ppf.OSLAM_E_INVALID
+    with pytest.raises(ValueError):
+        ppf.depth_to_cloud(img.astype(np.int32), 10.0, 10.0, 4.0, 4.0)
+    if not torch.cuda.is_available():
+        with pytest.raises(ppf.OslamError) as e:
+            ppf.depth_to_cloud(img, 10.0, 10.0, 4.0, 4.0)
+        assert e.value.code == ppf.OSLAM_E_DEVICE
