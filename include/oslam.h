@@ -67,11 +67,11 @@ typedef struct oslam_stats {
     uint64_t num_top;              /* cells with count > threshold * max */
     uint32_t max_count;            /* largest cell */
     uint32_t num_emitted;          /* records the vote kernel wrote before the final filter */
-    float ms_vote;                 /* scene-key + vote kernels of the call, HIP events on the launch stream */
+    float ms_vote;                 /* scene-key, hit-sort and vote kernels of the call, HIP events on the launch stream */
     float ms_total;                /* whole oslam_align call, host clock */
     uint32_t vote_launches;        /* launches of the vote kernel (one per batch of reference points) */
     float ms_vote_kernel;          /* sum over the vote-kernel launches alone (HIP events around each) */
-    float ms_key_kernel;           /* sum over the scene-key kernel launches alone */
+    float ms_key_kernel;           /* sum over the scene-key and hit-sort kernel launches */
     uint32_t reserved[3];
 } oslam_stats;
 

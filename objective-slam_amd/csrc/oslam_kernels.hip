@@ -8,16 +8,22 @@
  *   model build : pair key -> per-slice open-addressing table -> bucketed
  *                 4-byte pair entries (two counting passes, no sort); union table
  *                 of all keys; bitset of the distance bins that can reach a key;
+ *                 entries ordered inside each bucket for the LDS banks;
  *   scene keys  : per (reference r, tile of scene points): distance bin of every
  *                 pair, unreachable bins dropped, the rest compacted in LDS; full
  *                 key -> union-table probe -> per-reference hit list
  *                 {key, T_s_g*s_i, theta_v} written by wave-aggregated appends;
- *   voting      : one workgroup per (scene reference point, model slice):
- *                 hit -> slice table probe -> wave-cooperative, prefetched sweep
- *                 of the bucket (16 bytes = 4 entries per lane) -> integer alpha
- *                 bin -> LDS accumulator [1024 model refs][32 alpha bins]; votes
- *                 near a bin edge queued and re-evaluated with the reference's
- *                 float sequence; in-kernel peak extraction.
+ *   hit sort    : per reference point, hits ordered by key (LDS radix sort) and
+ *                 the list of runs of equal keys;
+ *   voting      : one workgroup per (scene reference point, model slice): runs ->
+ *                 slice table probes -> items (bucket, hits) in scratch; the work
+ *                 in units of (chunk of 256 entries, hit), handed to the 16 waves
+ *                 in grains; a wave streams a bucket once for all hits that share
+ *                 it (16 bytes = 4 entries per lane, loads two steps ahead) ->
+ *                 integer alpha bin -> LDS accumulator [1024 model refs][32 alpha
+ *                 bins]; votes near a bin edge queued and re-evaluated with the
+ *                 reference's float sequence; in-kernel peak extraction;
+ *   clustering  : scores of the candidate poses (one wave per pose).
  */
 #include <hip/hip_runtime.h>
 
