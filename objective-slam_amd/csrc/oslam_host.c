@@ -1201,8 +1201,10 @@ int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, siz
     if (rc != OSLAM_OK) return rc;
     /* peaks above the local threshold: a superset of what survives the global one */
     n = oslam_filter_cells(m->h_out, n, m->params.vote_count_threshold, cnt.gmax);
-    oslam_sort_cells(m->h_out, n);
-    if (n > cap) n = cap;     /* the strongest peaks are kept; cap is sized by the caller */
+    if (n > cap) {            /* the strongest peaks are kept; cap is sized by the caller */
+        oslam_sort_cells(m->h_out, n);
+        n = cap;
+    }                         /* otherwise the order is left to oslam_align_finish, which orders the union */
     memcpy(cells_out, m->h_out, sizeof(oslam_cell) * n);
     *n_out = n;
     *local_max_out = cnt.gmax;
