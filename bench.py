@@ -196,6 +196,16 @@ def main():
                          "path_alg_bytes_per_step": path_bytes, "path_kernels_ms_per_step": ms_path,
                          "torch_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps},
         }
+        # What binds the vote kernel in fact: the LDS atomics, one per vote.  Peak from
+        # tools/micro/lds_atomic_bench.hip on MI355X: one conflict-free ds_add_u32 wave-instruction
+        # (64 lane-atomics) per 4.4 cycles per CU, 256 CUs, 2.4 GHz.
+        lds_peak = 256 * 64 * 2.4e9 / 4.4
+        out["roofline_lds_atomic"] = {"bound": "lds_atomic", "kernel": "k_vote", "unit": "votes/s",
+                                      "achieved": st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3),
+                                      "peak": lds_peak,
+                                      "frac": st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3) / lds_peak,
+                                      "note": "secondary, informational: votes per second of vote-kernel time against the "
+                                              "measured conflict-free LDS-atomic rate of the chip"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mp, mn, sp, sn, df, d_dist)
             out["pose_recall_at_1deg"] = pose_recall(ppf, synth, mode)
