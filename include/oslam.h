@@ -52,7 +52,8 @@ typedef struct oslam_params {
     int vote_mode;                 /* OSLAM_VOTE_EXACT (default) or OSLAM_VOTE_FAST */
     int shard_rank;                /* scene reference points r = df*(rank + world*t); default 0 */
     int shard_world;               /* default 1 */
-    unsigned max_cells;            /* capacity of the peak-record buffer, default 1<<22 */
+    unsigned max_cells;            /* initial capacity of the peak-record buffer, default 1<<22; it grows (to at most
+                                    * 2^28 records) when more cells than that lie above the threshold */
     int reserved[6];
 } oslam_params;
 

@@ -952,8 +952,31 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
         rc = run_votes(m, s, g, cnt, &ms2, &msv, &msk, &launches);
         if (rc != OSLAM_OK) return rc;
         cnt->gmax = g;
-        if (cnt->out_count > m->out_cap)
-            return fail(OSLAM_E_LIMIT, "more accumulator peaks than params.max_cells");
+        if (cnt->out_count > m->out_cap) {
+            /* even the exactly thresholded set is larger than the record buffer: the count is known now, so
+             * the buffers grow to it (up to 2^28 records = 4 GiB) and the launch is repeated */
+            const uint64_t need = (uint64_t)cnt->out_count + cnt->out_count / 8 + 1024;
+            oslamk_cell *d_new = NULL;
+            oslam_cell *h_new;
+            if (need > ((uint64_t)1 << 28))
+                return fail(OSLAM_E_LIMIT, "more than 2^28 accumulator peaks above the threshold");
+            if (hipMalloc((void **)&d_new, sizeof(oslamk_cell) * need) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(OSLAM_E_NOMEM, "no device memory for the accumulator peaks");
+            }
+            h_new = (oslam_cell *)malloc(sizeof(oslam_cell) * need);
+            if (!h_new) { (void)hipFree(d_new); return fail(OSLAM_E_NOMEM, "host allocation failed"); }
+            (void)hipFree(m->d_out);
+            free(m->h_out);
+            m->d_out = d_new;
+            m->h_out = h_new;
+            m->out_cap = (uint32_t)need;
+            rc = run_votes(m, s, g, cnt, &ms2, &msv, &msk, &launches);
+            if (rc != OSLAM_OK) return rc;
+            cnt->gmax = g;
+            if (cnt->out_count > m->out_cap)
+                return fail(OSLAM_E_LIMIT, "more accumulator peaks than the record buffer after growing it");
+        }
     }
     if (getenv("OSLAM_PROF"))      /* only a -DVOTE_PROF build fills these */
         fprintf(stderr, "[oslam prof] k_vote wave cycles: to the end of voting %llu, to the barrier after it %llu, "

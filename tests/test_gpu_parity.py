@@ -251,9 +251,10 @@ def test_record_buffer_overflow_takes_the_second_pass(ppf, oracle, built_lib, ca
     sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], params=par)
     mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
     ocells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], 1, c["d"], 0.4)
-    if len(ocells) > 8:
-        with pytest.raises(ppf.OslamError):        # even the exact set does not fit: reported, not truncated
-            mo.ppf_lookup(sc)
+    assert len(ocells) > 8
+    T = mo.ppf_lookup(sc)                          # even the exact set does not fit: the buffer grows, third launch
+    assert cells_equal(mo.last_cells()[0], ocells) and mo.stats["vote_launches"] == 3
+    assert np.array_equal(T, oracle.pose_from_cells(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"])[1])
     par = ppf.default_params(max_cells=max(16, 2 * len(ocells)))
     mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=par)
     mo.ppf_lookup(sc)
