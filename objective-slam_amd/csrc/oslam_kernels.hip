@@ -339,20 +339,17 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
-/* v_mul_hi_u32_u24 / v_mul_u32_u24 by PC_T24_SCALE.  The C expressions select exactly these two
- * instructions; the empty asm keeps the compiler from fusing (hi << 2) and lo into a 64-bit shift
- * (v_alignbit + v_and) and, unlike instructions written in asm, costs no padding s_nop. */
-__device__ __forceinline__ uint32_t mul24_hi_7680(uint32_t a)
+/* bin and position inside the bin of one vote, from tm8 = (hit base - 4*theta_u) << 8 (the 24-bit
+ * difference in the upper 24 bits of the word: the left shift drops what lies above it):
+ * tm8 * 30 = tm24 * 7680 = bin * 2^32 + position * 2^32, one v_mad_u64_u32 (4.3 cycles per
+ * wave-instruction, like each of the two 24-bit multiplies it replaces).  The empty asm keeps the
+ * compiler from fusing (bin << 2) with the low word into a 64-bit shift. */
+__device__ __forceinline__ void vote_product(uint32_t tm8, uint32_t &bin, uint32_t &pos)
 {
-    uint32_t r = (uint32_t)(((unsigned long long)(a & 0xffffffu) * PC_T24_SCALE) >> 32);
-    asm("" : "+v"(r));
-    return r;
-}
-__device__ __forceinline__ uint32_t mul24_lo_7680(uint32_t a)
-{
-    uint32_t r = (uint32_t)((unsigned long long)(a & 0xffffffu) * PC_T24_SCALE);
-    asm("" : "+v"(r));
-    return r;
+    const unsigned long long p = (unsigned long long)tm8 * 30ull;
+    bin = (uint32_t)(p >> 32);
+    pos = (uint32_t)p;
+    asm("" : "+v"(bin));
 }
 /* a value every lane holds, moved to scalar registers */
 __device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -476,12 +473,12 @@ struct VoteRegs {
                                               unsigned long long fmask) const
     {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t csmv = pc_vote_base_t24(th);
+        const uint32_t csmv = pc_vote_base_t24(th) << 8;     /* see vote_product */
         const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_u32 *)acc;        /* the accumulator's LDS address */
         uint32_t wa[4], rowb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            wa[j] = w[j] << 2;
+            wa[j] = w[j] << 10;                            /* 4 * theta_u, shifted like the hit base */
             /* byte offset of the entry's accumulator row, or of the lane's trash word */
             rowb[j] = (w[j] >> 15) & 0x1ff80u;
             /* the partial variant issues its atomics from asm with absolute LDS addresses */
@@ -492,19 +489,17 @@ struct VoteRegs {
         const unsigned long long live = FULL ? ~0ull : __ballot(4u * (uint32_t)lane < d.left);
         auto one_hit = [&](int i) {
             const uint32_t csm = readlane_u(csmv, i);
-            uint32_t tm[4], addr[4];
+            uint32_t addr[4], pos[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                tm[j] = csm - wa[j];
-                addr[j] = rowb[j] + (mul24_hi_7680(tm[j]) << 2);
+                uint32_t bin;
+                vote_product(csm - wa[j], bin, pos[j]);
+                addr[j] = rowb[j] + (bin << 2);
             }
             if (MODE == 0) {
                 /* position inside the (shifted) bin, in 2^-32 bin: below PC_T24_EDGE = within the margin
                  * of an edge.  One compare of the smallest of the four decides whether anything is
                  * queued; lanes past the bucket end only ever cause a look that finds nothing. */
-                uint32_t pos[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) pos[j] = mul24_lo_7680(tm[j]);
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
                 const bool forced = FORCED && ((fmask >> i) & 1ull);
                 if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))

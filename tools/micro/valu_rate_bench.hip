@@ -24,6 +24,7 @@
 #define I_MULF32(n) "v_mul_f32 %" #n ", %8, %9\n"
 #define I_CVT(n) "v_cvt_f32_u32 %" #n ", %8\n"
 #define I_FMA(n) "v_fma_f32 %" #n ", %8, %9, %" #n "\n"
+#define I_MAD64(n) "v_mad_u64_u32 %" #n ", vcc, %8, %9, 0\n"
 template <int W>
 __global__ __launch_bounds__(1024) void k(unsigned long long *cyc, uint32_t *sink)
 {
@@ -42,6 +43,18 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *cyc, uint32_t *sin
     if (W == 8) { BODY(I_MULF32) }
     if (W == 9) { BODY(I_CVT) }
     if (W == 10) { BODY(I_FMA) }
+    if (W == 11) {
+        unsigned long long q[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+        for (int i = 0; i < ITER; i++) {
+#pragma unroll
+            for (int k = 0; k < REP / 8; k++) {
+                asm volatile(I_MAD64(0) I_MAD64(1) I_MAD64(2) I_MAD64(3) I_MAD64(4) I_MAD64(5) I_MAD64(6) I_MAD64(7)
+                             : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
+                             : "v"(a), "v"(b) : "vcc");
+            }
+        }
+        r[0] += (uint32_t)(q[0] + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + q[7]);
+    }
     __syncthreads();
     const long long t1 = clock64();
     if (threadIdx.x == 0) cyc[blockIdx.x] = (unsigned long long)(t1 - t0);
@@ -72,5 +85,6 @@ int main()
     run<8>("v_mul_f32", d_cyc, d_sink);
     run<9>("v_cvt_f32_u32", d_cyc, d_sink);
     run<10>("v_fma_f32", d_cyc, d_sink);
+    run<11>("v_mad_u64_u32", d_cyc, d_sink);
     return 0;
 }
