@@ -145,7 +145,7 @@ PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const 
  * i.e. the bin is v_mul_hi_u32_u24(t24, 7680) and the position v_mul_u32_u24(t24, 7680).
  * The float rounding of the reference's own sequence (cross/dot products, atan2f,
  * + pi, quantisation) moves alpha by < 2e-5 bin against this value (bound in
- * DESIGN.md), so whenever the position is further than the margin (2.3e-4 bin)
+ * DESIGN.md), so whenever the position is further than the margin (1.14e-4 bin)
  * from a bin edge the bin is the reference's; otherwise the vote is re-evaluated
  * with pc_alpha_bin_table.  The margin is added to t24 first, so that one unsigned
  * compare of the position finds both sides of an edge; the bin read from the
@@ -154,7 +154,7 @@ PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const 
  * Result: identical bins at a fraction of the arithmetic and 4 bytes per vote. */
 #define PC_T22_TURN 4194304u                  /* 2^22 units per turn */
 #define PC_T24_SCALE 7680u                    /* 30 bins * 2^8 */
-#define PC_T24_MARGIN 128u                    /* in t24 units: 128 * 30 / 2^24 = 2.3e-4 bin */
+#define PC_T24_MARGIN 64u                     /* in t24 units: 64 * 30 / 2^24 = 1.14e-4 bin (5.7 x the bound) */
 #define PC_T24_EDGE (2u * PC_T24_MARGIN * PC_T24_SCALE)   /* position (2^-32 bin) below which a shifted vote is near an edge */
 #define PC_T22_FORCE 0xffffffffu              /* "always re-evaluate" marker */
 #define PC_T22_PER_RAD 667544.214430109f      /* 2^22 / (2 pi) */
