@@ -97,6 +97,7 @@ def main():
     model = ppf.Model(mp, mn, d_dist=d_dist, params=par)       # table resident in HBM
     t_build = time.time() - t0
     scene = ppf.Scene(sp, sn, d_dist=d_dist, ref_point_downsample_factor=df, params=par)   # resident in HBM
+    model.prepare(scene)      # device scratch pool and pose-tail tables: set-up, like the model table itself
     log("[rank %d] model build %.3fs, d_dist %.5f, df %d" % (rank, t_build, d_dist, df))
 
     def step():

@@ -131,6 +131,11 @@ void oslam_scene_destroy(oslam_scene *s);
  * T_rowmajor receives the best model->scene pose.  stats may be NULL. */
 int oslam_align(oslam_model *m, oslam_scene *s, float T_rowmajor[16], oslam_stats *stats);
 
+/* Optional: everything oslam_align would allocate on first use for this pair (the scratch pool of the
+ * device -- mapping 32 GiB takes about a second -- and the frame tables of the device pose tail), done
+ * ahead of time so that the first registration is as fast as the following ones. */
+int oslam_align_prepare(oslam_model *m, oslam_scene *s);
+
 /* ppf_registration (include/ppf.h:9-15, src/cuda/ppf.cu:29-106): every scene
  * against every model; T_out[(i*n_models + j)*16 ..] = pose of model j in
  * scene i.  model_weights is accepted and ignored, as in the reference

@@ -1174,6 +1174,19 @@ static int finish_cells(oslam_model *m, oslam_scene *s, oslam_cell *cells, size_
     return OSLAM_OK;
 }
 
+int oslam_align_prepare(oslam_model *m, oslam_scene *s)
+{
+    int rc, batch = 0;
+    scratch_pool *pool = NULL;
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    rc = ensure_hit_scratch(m, s, &pool, &batch);
+    if (rc != OSLAM_OK) return rc;
+    if (pose_gpu_from(m)) rc = pose_tables(m, s);
+    return rc;
+}
+
 int oslam_align(oslam_model *m, oslam_scene *s, float T[16], oslam_stats *stats)
 {
     int rc;

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "oslam_scene_create": (_i, [_vp, _vp, _sz, _sz, _f, _u, C.POINTER(Params), C.POINTER(_vp)]),
     "oslam_scene_destroy": (None, [_vp]),
     "oslam_align": (_i, [_vp, _vp, _vp, C.POINTER(Stats)]),
+    "oslam_align_prepare": (_i, [_vp, _vp]),
     "oslam_ppf_registration": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp, _u, _f, _i, _i, _i, _i, _vp, _vp]),
     "oslam_ht_dist": (_i, [_vp, _vp, _vp]),
     "oslam_ply_read": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
@@ -257,6 +258,10 @@ class Model:
     def SetModelPointVoteWeights(self, weights):
         w = np.ascontiguousarray(weights, np.float32)
         _check(lib().oslam_model_set_point_weights(self._h, _p(w), len(w)))
+
+    def prepare(self, scene):
+        """Allocate what the first ppf_lookup of this pair would (device scratch pool, pose-tail tables)."""
+        _check(lib().oslam_align_prepare(self._h, scene._h))
 
     def ppf_lookup(self, scene, allow_no_votes=False):
         """Model::ppf_lookup (model.cu:269-306) + extraction (ppf.cu:74-93)."""
