@@ -92,12 +92,13 @@ void oslam_T_g_full(const float *xyz, const float *nrm, size_t idx0, size_t step
 void oslam_T_g_rows(const float *xyz, const float *nrm, const uint32_t *idx, size_t n,
                     float *rows_out)
 {
-    size_t i;
-    for (i = 0; i < n; i++) {
+    long i;
+#pragma omp parallel for schedule(static) num_threads(pose_threads(n))
+    for (i = 0; i < (long)n; i++) {
         float T[16];
-        size_t r = idx ? idx[i] : i;
+        size_t r = idx ? idx[i] : (size_t)i;
         oslam_build_T_g(xyz + 3 * r, nrm + 3 * r, T);
-        memcpy(rows_out + 8 * i, T + 4, 8 * sizeof(float));
+        memcpy(rows_out + 8 * (size_t)i, T + 4, 8 * sizeof(float));
     }
 }
 
