@@ -73,7 +73,10 @@ typedef struct oslam_stats {
     uint32_t vote_launches;        /* launches of the vote kernel (one per batch of reference points) */
     float ms_vote_kernel;          /* sum over the vote-kernel launches alone (HIP events around each) */
     float ms_key_kernel;           /* sum over the scene-key and hit-sort kernel launches */
-    uint32_t reserved[3];
+    uint32_t reserved0;
+    uint64_t num_pairs_probed;     /* of num_scene_ppfs, the pairs whose distance bin can reach a model key: they are keyed
+                                    * and probed; the others cannot hit and are dropped by the distance test alone */
+    uint64_t scratch_bytes;        /* size of the device's hit-list pool after this call */
 } oslam_stats;
 
 /* One accumulator peak: code = s_r << 32 | m_r << 6 | alpha_idx (kernel.cu:549). */
@@ -207,14 +210,36 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
                      int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
                      const float *model_point_weights, float T_rowmajor[16], float *poses_out);
 
-/* ---- multi-GPU: scene reference points shard across ranks (one process per
- * GPU).  oslam_align_local runs the vote kernel for this scene's shard
- * (params.shard_rank/shard_world at oslam_scene_create) and returns up to cap
- * peak records (count > threshold * local max) in cells_out (host memory) plus
- * the local maximum; the caller all-gathers records and maxima (RCCL) and every
- * rank, or rank 0, calls oslam_align_finish on the union. */
+/* ---- multi-GPU: scene reference points shard across ranks (one process per GPU;
+ * params.shard_rank / shard_world at oslam_scene_create), model tables replicated.  The reference
+ * has no multi-GPU code (src/cuda/ppf.cu:45 picks one device); its one call does everything
+ * (include/ppf.h:9-15), and so does oslam_align_multi.
+ *
+ * RCCL form.  oslam_comm wraps an RCCL communicator: rank 0 makes an id (oslam_comm_unique_id),
+ * hands its OSLAM_COMM_ID_BYTES bytes to the other ranks by any means (MPI, a file, a
+ * torch.distributed broadcast), every rank calls oslam_comm_create.  oslam_align_multi = this
+ * rank's votes, all-reduce(MAX) of the vote maxima (the threshold is global, model.cu:164-170),
+ * all-gather of the peak records above the global threshold -- device buffers end to end, exact
+ * sizes, nothing truncated -- and the pose tail on the union; every rank returns the same pose. */
+typedef struct oslam_comm oslam_comm;
+#define OSLAM_COMM_ID_BYTES 128
+int oslam_comm_unique_id(void *id_out);
+int oslam_comm_create(const void *id, int rank, int world, int dev, oslam_comm **out);
+void oslam_comm_destroy(oslam_comm *c);
+int oslam_align_multi(oslam_model *m, oslam_scene *s, oslam_comm *c, float T_rowmajor[16], oslam_stats *stats);
+
+/* Host-buffer form of the same exchange, for callers with their own transport (and the CPU tests
+ * over gloo).  oslam_align_local runs this rank's votes and reports the number of peak records
+ * above the LOCAL threshold in *n_out and the local maximum; the records stay with the model.  It
+ * copies them to cells_out when they fit cap; when they do not, it copies the cap strongest and
+ * returns OSLAM_E_LIMIT -- never a silent cut (cap 0 with cells_out NULL just asks for the
+ * numbers and returns OSLAM_OK).  After the maxima have been exchanged, oslam_local_peaks hands
+ * out the records above threshold * global_max (fewer); OSLAM_E_LIMIT with the needed number in
+ * *n_out when cap is too small, call again.  Every rank, or rank 0, then calls
+ * oslam_align_finish on the gathered union. */
 int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, size_t cap,
                       size_t *n_out, uint32_t *local_max_out, oslam_stats *stats);
+int oslam_local_peaks(oslam_model *m, uint32_t global_max, oslam_cell *cells_out, size_t cap, size_t *n_out);
 int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, size_t n,
                        uint32_t global_max, float T_rowmajor[16], oslam_stats *stats);
 
@@ -242,6 +267,11 @@ int oslam_last_cells(oslam_model *m, oslam_cell *cells_out, float *poses_out, si
 /* Launch stream for all kernels of this thread's calls (hipStream_t as void*;
  * NULL = the default stream).  bench.py passes torch's current stream. */
 int oslam_set_stream(void *hip_stream);
+/* Calls that launch on one device are serialised inside the library (one lock per device: they share
+ * the device's hit-list pool, which grows to what a registration needs, at most OSLAM_SCRATCH_GIB GiB,
+ * default 4, unless a single reference point needs more).  oslam_release_scratch frees the pool and the
+ * other per-device work space; the next call allocates them again. */
+int oslam_release_scratch(int dev);
 const char *oslam_last_error(void);
 /* Threads of the host stage (poses and clustering of the gathered peaks); 0 = OpenMP's default,
  * capped at 16.  Launchers that export OMP_NUM_THREADS=1 per rank can raise it here. */

@@ -10,10 +10,13 @@
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+
+#include <rccl/rccl.h>
 
 #include "oslam.h"
 #include "oslam_kernels.h"
@@ -129,6 +132,11 @@ struct oslam_model {
     oslamk_cell *d_out;
     uint32_t out_cap;
     oslam_cell *h_out;
+    /* multi-GPU: peaks of the last oslam_align_local (in h_out), survivors of this rank (device) */
+    size_t n_local;
+    uint32_t local_max;
+    oslamk_cell *d_union;
+    size_t union_cap;
     /* frames T_g of the model points [M][16] and the point weights, for the pose tail on the device */
     float *d_Tm16, *d_weights;
     /* last result: on the host, or still on the device (pose tail ran there) until a tap asks for it */
@@ -305,6 +313,8 @@ void oslam_model_destroy(oslam_model *m)
     if (m->table.reach) (void)hipFree(m->table.reach);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_union) (void)hipFree(m->d_union);
+    if (m->table.uinfo) (void)hipFree(m->table.uinfo);
     if (m->d_Tm16) (void)hipFree(m->d_Tm16);
     if (m->d_weights) (void)hipFree(m->d_weights);
     if (m->d_pose_cells) (void)hipFree(m->d_pose_cells);
@@ -315,6 +325,19 @@ void oslam_model_destroy(oslam_model *m)
     free(m->last_poses);
     free(m->h_slots);
     free(m);
+}
+
+/* table.uinfo: the bucket of every union-table slot in every slice (what the vote kernel reads) */
+static int build_uinfo(oslam_model *m)
+{
+    int rc = OSLAM_OK;
+    const size_t bytes = sizeof(oslamk_uinfo) * (size_t)m->table.n_slices * (size_t)m->table.ucap;
+    if (m->table.uinfo) { (void)hipFree(m->table.uinfo); m->table.uinfo = NULL; }
+    HIPCHK(hipMalloc((void **)&m->table.uinfo, bytes));
+    HIPCHK(hipMemsetAsync(m->table.uinfo, 0, bytes, (hipStream_t)g_stream));
+    KCHK(oslamk_uinfo_build(m->table, g_stream));
+done:
+    return rc;
 }
 
 int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
@@ -377,7 +400,8 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     {
         uint32_t sum = 0, lg = 16;
         for (s = 0; s < n_slices; s++) sum += h_small[s];
-        while ((1u << lg) < 4u * sum && lg < 30) lg++;
+        while ((1u << lg) < 4u * sum && lg < OSLAMK_RUN_SHIFT) lg++;
+        if ((1u << lg) < 2u * sum) { rc = fail(OSLAM_E_LIMIT, "more distinct pair keys than the union table can index"); goto done; }
         m->table.ucap = 1u << lg;
         m->table.ushift = 32 - lg;
         HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)m->table.ucap));
@@ -408,6 +432,8 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
         HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
     KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->ent, g_stream));
     if (!getenv("OSLAM_NO_SPREAD")) KCHK(oslamk_bucket_spread(m->table, m->ent, g_stream));   /* the switch is for A/B measurements */
+    rc = build_uinfo(m);
+    if (rc != OSLAM_OK) goto done;
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
 
     m->out_cap = m->params.max_cells;
@@ -427,15 +453,17 @@ done:
 /* ------------------------------------------------------------------------
  * persistent model database: one file per built model
  * ---------------------------------------------------------------------- */
+static int build_uinfo(oslam_model *m);
+
 #define OSLAM_DB_MAGIC 0x4c444d4f534c4f00ull     /* "\0OLSOMDL" */
-#define OSLAM_DB_VERSION 3u                      /* table layout: 16-B slots, e4 = m_r<<22 | theta (2^-22 turn) */
+#define OSLAM_DB_VERSION 4u                      /* table layout: 16-B slots, e4 = m_r<<22 | theta (2^-22 turn); checksum covers the header */
 typedef struct db_header {
     uint64_t magic;
     uint32_t version, vote_mode;
     uint32_t n_points, n_slices, cap, shift, ucap, ushift, n_entries, has_uv;
     uint64_t num_model_keys;
     float d_dist, inv_d_dist;
-    uint64_t checksum;                           /* FNV-1a 64 over every payload byte, in file order */
+    uint64_t checksum;                           /* FNV-1a 64 over the header (this field zero) and every payload byte, in file order */
 } db_header;
 
 static uint64_t fnv64(uint64_t h, const void *p, size_t n)
@@ -483,6 +511,13 @@ done:
     return rc;
 }
 
+static uint32_t log2_exact(uint32_t v)            /* v a power of two */
+{
+    uint32_t lg = 0;
+    while ((1u << lg) < v) lg++;
+    return lg;
+}
+
 int oslam_model_save(const oslam_model *m, const char *path)
 {
     int rc = OSLAM_OK;
@@ -510,7 +545,8 @@ int oslam_model_save(const oslam_model *m, const char *path)
     f = fopen(path, "wb");
     if (!f) return fail(OSLAM_E_INVALID, "cannot open the model file for writing");
     if (fwrite(&hd, sizeof hd, 1, f) != 1) { rc = fail(OSLAM_E_INVALID, "short write"); goto done; }
-    /* payload: host cloud, weights, then the device arrays */
+    /* checksummed: the header (checksum field still zero), host cloud, weights, then the device arrays */
+    sum = fnv64(sum, &hd, sizeof hd);
     sum = fnv64(sum, m->c.h_xyz, 12 * n);
     sum = fnv64(sum, m->c.h_nrm, 12 * n);
     sum = fnv64(sum, m->weights, 4 * n);
@@ -536,11 +572,12 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
 {
     int rc = OSLAM_OK;
     FILE *f = NULL;
-    db_header hd;
+    db_header hd, hz;
     oslam_model *m = NULL;
     float *xyz = NULL, *nrm = NULL;
+    oslamk_slot *h_slots = NULL;
     uint64_t sum = 0xcbf29ce484222325ull;
-    size_t n, n_pairs;
+    size_t n, n_pairs, n_slots, i;
     if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
     *out = NULL;
     if (!path) return fail(OSLAM_E_INVALID, "path is NULL");
@@ -548,13 +585,22 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     if (!f) return fail(OSLAM_E_INVALID, "cannot open the model file");
     if (fread(&hd, sizeof hd, 1, f) != 1 || hd.magic != OSLAM_DB_MAGIC) { rc = fail(OSLAM_E_INVALID, "not a model file"); goto done; }
     if (hd.version != OSLAM_DB_VERSION) { rc = fail(OSLAM_E_INVALID, "model file has another table layout version"); goto done; }
+    /* every field a kernel indexes with is checked against the others: a stale or damaged header must not
+     * reach the GPU (slot_of() shifts by `shift`, the vote kernel dereferences uv in exact mode) */
     n = hd.n_points;
     if (n < 2 || n > 46340 || hd.n_slices != (n + OSLAMK_SLICE - 1) / OSLAMK_SLICE || hd.n_slices > 64 ||
-        hd.cap == 0 || (hd.cap & (hd.cap - 1)) || hd.ucap == 0 || (hd.ucap & (hd.ucap - 1)) || hd.cap > (1u << 26) ||
-        !(hd.d_dist > 0.0f)) {
+        hd.cap < 2 || (hd.cap & (hd.cap - 1)) || hd.cap > (1u << 26) || hd.ucap < 2 || (hd.ucap & (hd.ucap - 1)) ||
+        hd.ucap > (1u << OSLAMK_RUN_SHIFT) || hd.shift != 32u - log2_exact(hd.cap) || hd.ushift != 32u - log2_exact(hd.ucap) ||
+        !(hd.d_dist > 0.0f) || hd.inv_d_dist != 1.0f / hd.d_dist || hd.has_uv > 1u ||
+        hd.vote_mode > (uint32_t)OSLAM_VOTE_FAST || (hd.vote_mode != (uint32_t)OSLAM_VOTE_FAST && !hd.has_uv) ||
+        (uint64_t)hd.n_entries > (uint64_t)n * (n - 1) + 3ull * (uint64_t)hd.cap * hd.n_slices ||
+        hd.num_model_keys > (uint64_t)hd.ucap + 1) {
         rc = fail(OSLAM_E_INVALID, "model file header is inconsistent");
         goto done;
     }
+    hz = hd;
+    hz.checksum = 0;
+    sum = fnv64(sum, &hz, sizeof hz);
     m = (oslam_model *)calloc(1, sizeof *m);
     if (!m) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
     if (params) m->params = *params; else oslam_params_default(&m->params);
@@ -569,14 +615,24 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     xyz = (float *)malloc(12 * n);
     nrm = (float *)malloc(12 * n);
     m->weights = (float *)malloc(4 * n);
-    if (!xyz || !nrm || !m->weights) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
-    if (fread(xyz, 12, n, f) != n || fread(nrm, 12, n, f) != n || fread(m->weights, 4, n, f) != n) {
+    n_slots = (size_t)hd.cap * hd.n_slices;
+    h_slots = (oslamk_slot *)malloc(sizeof(oslamk_slot) * n_slots);
+    if (!xyz || !nrm || !m->weights || !h_slots) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    if (fread(xyz, 12, n, f) != n || fread(nrm, 12, n, f) != n || fread(m->weights, 4, n, f) != n ||
+        fread(h_slots, sizeof(oslamk_slot), n_slots, f) != n_slots) {
         rc = fail(OSLAM_E_INVALID, "model file is truncated");
         goto done;
     }
     sum = fnv64(sum, xyz, 12 * n);
     sum = fnv64(sum, nrm, 12 * n);
     sum = fnv64(sum, m->weights, 4 * n);
+    sum = fnv64(sum, h_slots, sizeof(oslamk_slot) * n_slots);
+    /* no bucket may reach past the entry arrays */
+    for (i = 0; i < n_slots; i++)
+        if (h_slots[i].key != 0 && ((uint64_t)h_slots[i].start + h_slots[i].len > hd.n_entries || (h_slots[i].start & 3u))) {
+            rc = fail(OSLAM_E_INVALID, "model file: a bucket lies outside the entry arrays");
+            goto done;
+        }
     rc = cloud_upload(&m->c, xyz, nrm, n, 12);
     if (rc != OSLAM_OK) goto done;
     m->d_dist = hd.d_dist;
@@ -589,20 +645,25 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     m->n_entries = hd.n_entries;
     m->num_model_keys = hd.num_model_keys;
     n_pairs = hd.n_entries ? hd.n_entries : 1;
-    HIPCHK(hipMalloc((void **)&m->table.slots, sizeof(oslamk_slot) * (size_t)hd.cap * hd.n_slices));
+    HIPCHK(hipMalloc((void **)&m->table.slots, sizeof(oslamk_slot) * n_slots));
     HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap));
     HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
     HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * n_pairs));
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
     if (hd.has_uv) HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
-    rc = db_read_dev(f, m->table.slots, sizeof(oslamk_slot) * (size_t)hd.cap * hd.n_slices, &sum);
-    if (rc == OSLAM_OK) rc = db_read_dev(f, m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap, &sum);
+    HIPCHK(hipMemcpy(m->table.slots, h_slots, sizeof(oslamk_slot) * n_slots, hipMemcpyHostToDevice));
+    rc = db_read_dev(f, m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap, &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.e4, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.uv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
     if (rc != OSLAM_OK) goto done;
     if (sum != hd.checksum) { rc = fail(OSLAM_E_INVALID, "model file checksum mismatch"); goto done; }
+    m->h_slots = h_slots;                         /* the bucket tap reads it */
+    h_slots = NULL;
+    rc = build_uinfo(m);
+    if (rc != OSLAM_OK) goto done;
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
     m->out_cap = m->params.max_cells;
     HIPCHK(hipMalloc((void **)&m->d_counters, sizeof(oslamk_counters)));
     HIPCHK(hipMalloc((void **)&m->d_out, sizeof(oslamk_cell) * (size_t)m->out_cap));
@@ -612,6 +673,7 @@ done:
     if (f) fclose(f);
     free(xyz);
     free(nrm);
+    free(h_slots);
     if (rc != OSLAM_OK) { oslam_model_destroy(m); return rc; }
     *out = m;
     return OSLAM_OK;
@@ -625,6 +687,7 @@ int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint
     if (table_bytes)
         *table_bytes = sizeof(oslamk_slot) * (uint64_t)m->table.cap * (uint64_t)m->table.n_slices +
                        sizeof(uint32_t) * (uint64_t)m->table.ucap + sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32) +
+                       sizeof(oslamk_uinfo) * (uint64_t)m->table.ucap * (uint64_t)m->table.n_slices +
                        (uint64_t)m->n_entries * (4 + 2 + (m->ent.uv ? 8 : 0)) + 24ull * (uint64_t)m->c.n;
     return OSLAM_OK;
 }
@@ -784,104 +847,191 @@ static int check_pair(const oslam_model *m, const oslam_scene *s)
 }
 
 /* Scratch for the hit lists of one batch of reference points: one pool per device, shared by all
- * models (it is only live inside an align call; like the reference, calls on one device are not
- * re-entrant).  Up to OSLAM_SCRATCH_GIB GiB (default 32, or a quarter of the free device memory if that is less), at least one reference point's worth. */
+ * models and only live inside a call (calls on one device are serialised by the pool's lock).  The
+ * lists are sized by demand: a counting kernel gives, per reference point, the number of scene pairs
+ * that can reach a model key at all (an upper bound of its hits, 16 % above them on the bench scene);
+ * the host turns the counts into offsets and cuts the reference points into batches that fit the
+ * pool.  The pool grows to what a call needs, up to OSLAM_SCRATCH_GIB GiB (default 4; a single
+ * reference point that needs more still gets it); oslam_release_scratch frees it. */
 #define MAX_DEVICES 64
+#define MAX_BATCH_EVENTS 64
+#define SLOT_BYTES (sizeof(oslamk_pay) * 2 + sizeof(oslamk_run) + sizeof(uint32_t))
 typedef struct {
-    oslamk_hit *hits;
-    size_t hits_bytes;
-    uint32_t *hit_count;
-    size_t hit_count_cap;
+    pthread_mutex_t lock;
+    char *buf;                         /* hit arrays of one batch */
+    size_t bytes;
+    uint32_t *d_counts;                /* keep_count[cap], hit_count[cap], run_count[cap], hit_off[cap + 1 + batches] */
+    uint32_t *h_counts;                /* host staging: keep counts, then offsets */
+    size_t counts_cap;
+    hipEvent_t ev[4 + 3 * MAX_BATCH_EVENTS];
+    int have_events;
+    char *d_cluster;                   /* workspace of cluster_scores_on_device */
+    size_t cluster_bytes;
 } scratch_pool;
 static scratch_pool g_pool[MAX_DEVICES];
+static pthread_once_t g_pool_once = PTHREAD_ONCE_INIT;
 
-static int ensure_hit_scratch(const oslam_model *m, const oslam_scene *s, scratch_pool **pool_out, int *batch_out)
+static void pool_init_all(void)
 {
-    int rc = OSLAM_OK;
-    /* per reference point: hits in arrival order + sorted by key (16 B each), run list (8 B each, + end
-     * marker), and per slice the vote workgroup's items (16 B per run) + one running sum per 64 items */
-    const size_t S = (size_t)s->c.n, nsl = (size_t)m->table.n_slices;
-    const size_t per_ref = 2 * S * sizeof(oslamk_hit) + (S + 1) * 2 * sizeof(uint32_t) +
-                           nsl * (S * 16 + (S / 64 + 1) * sizeof(unsigned long long));
-    size_t want = per_ref * (size_t)(s->n_ref > 0 ? s->n_ref : 1), cap = (size_t)16 << 30;
+    int i;
+    for (i = 0; i < MAX_DEVICES; i++) pthread_mutex_init(&g_pool[i].lock, NULL);
+}
+
+/* the pool of a device, locked: every entry point that launches on the device holds it for the call */
+static scratch_pool *pool_lock(int dev)
+{
+    pthread_once(&g_pool_once, pool_init_all);
+    if (dev < 0 || dev >= MAX_DEVICES) return NULL;
+    pthread_mutex_lock(&g_pool[dev].lock);
+    return &g_pool[dev];
+}
+
+static void pool_unlock(scratch_pool *p)
+{
+    if (p) pthread_mutex_unlock(&p->lock);
+}
+
+int oslam_release_scratch(int dev)
+{
+    scratch_pool *p = pool_lock(dev);
+    int i;
+    if (!p) return fail(OSLAM_E_INVALID, "device ordinal out of range");
+    if (p->buf || p->d_counts || p->have_events || p->d_cluster) {
+        if (hipSetDevice(dev) != hipSuccess) { pool_unlock(p); return fail(OSLAM_E_DEVICE, "hipSetDevice failed"); }
+        if (p->buf) (void)hipFree(p->buf);
+        if (p->d_counts) (void)hipFree(p->d_counts);
+        if (p->d_cluster) (void)hipFree(p->d_cluster);
+        oslamk_pose_release();
+        if (p->have_events)
+            for (i = 0; i < 4 + 3 * MAX_BATCH_EVENTS; i++) (void)hipEventDestroy(p->ev[i]);
+    }
+    free(p->h_counts);
+    p->buf = NULL;
+    p->bytes = 0;
+    p->d_counts = NULL;
+    p->h_counts = NULL;
+    p->counts_cap = 0;
+    p->have_events = 0;
+    p->d_cluster = NULL;
+    p->cluster_bytes = 0;
+    pool_unlock(p);
+    return OSLAM_OK;
+}
+
+static size_t scratch_limit(void)
+{
     const char *env = getenv("OSLAM_SCRATCH_GIB");
-    scratch_pool *p;
-    size_t batch;
-    if (m->dev < 0 || m->dev >= MAX_DEVICES) return fail(OSLAM_E_LIMIT, "device ordinal too large");
-    p = &g_pool[m->dev];
-    if (env && atoi(env) > 0) {
-        cap = (size_t)atoi(env) << 30;
-    } else {
-        /* default: 32 GiB, or a quarter of what is free if that is less.  Mapping the pool costs about
-         * 40 ms per GiB once per process; the batches it allows cost 107 / 101 / 98 / 97 ms per
-         * 5k x 100k registration at 8 / 16 / 32 / 64 GiB (fewer, fuller launches) */
-        size_t fr = 0, tot = 0;
-        cap = (size_t)32 << 30;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (fr + p->hits_bytes) / 4 < cap) cap = (fr + p->hits_bytes) / 4;
+    return (size_t)(env && atoi(env) > 0 ? atoi(env) : 4) << 30;
+}
+
+/* per-reference counters for n_ref reference points, events */
+static int pool_reserve_counts(scratch_pool *p, size_t n_ref)
+{
+    int rc = OSLAM_OK, i;
+    if (!p->have_events) {
+        for (i = 0; i < 4 + 3 * MAX_BATCH_EVENTS; i++) HIPCHK(hipEventCreate(&p->ev[i]));
+        p->have_events = 1;
     }
-    if (want > cap) want = cap;
-    if (want < per_ref) want = per_ref;
-    if (p->hits_bytes < want) {
-        if (p->hits) { (void)hipFree(p->hits); p->hits = NULL; p->hits_bytes = 0; }
-        /* a refused allocation is retried at half the size, down to one reference point's worth */
-        while (hipMalloc((void **)&p->hits, want) != hipSuccess) {
-            (void)hipGetLastError();
-            p->hits = NULL;
-            if (want <= per_ref) return fail(OSLAM_E_NOMEM, "no device memory for the hit lists of one reference point");
-            want = want / 2 > per_ref ? want / 2 : per_ref;
-        }
-        p->hits_bytes = want;
+    if (p->counts_cap < n_ref) {
+        const size_t cap = n_ref + n_ref / 4 + 64;
+        if (p->d_counts) { (void)hipFree(p->d_counts); p->d_counts = NULL; }
+        free(p->h_counts);
+        p->h_counts = NULL;
+        p->counts_cap = 0;
+        /* offsets: one more than reference points per batch; a batch holds at least one reference point */
+        HIPCHK(hipMalloc((void **)&p->d_counts, sizeof(uint32_t) * (5 * cap + 2)));
+        p->h_counts = (uint32_t *)malloc(sizeof(uint32_t) * (3 * cap + 2));
+        if (!p->h_counts) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+        p->counts_cap = cap;
     }
-    batch = p->hits_bytes / per_ref;
-    if (batch > (size_t)s->n_ref) batch = (size_t)(s->n_ref > 0 ? s->n_ref : 1);
-    if (batch > 65535) batch = 65535;            /* grid.y of the scene-key kernel */
-    if (p->hit_count_cap < batch) {
-        if (p->hit_count) { (void)hipFree(p->hit_count); p->hit_count = NULL; p->hit_count_cap = 0; }
-        HIPCHK(hipMalloc((void **)&p->hit_count, sizeof(uint32_t) * 2 * batch));   /* hit counts, run counts */
-        p->hit_count_cap = batch;
-    }
-    *pool_out = p;
-    *batch_out = (int)batch;
 done:
     return rc;
 }
 
-/* the arrays of one batch inside the pool (sizes as in ensure_hit_scratch) */
-static void carve_scratch(oslamk_vote_args *a, const scratch_pool *pool, int batch, size_t S, size_t nsl)
+static int pool_reserve_slots(scratch_pool *p, size_t slots)
 {
-    char *p = (char *)pool->hits;
-    a->hits = (oslamk_hit *)p;
-    p += (size_t)batch * S * sizeof(oslamk_hit);
-    a->hits_sorted = (oslamk_hit *)p;
-    p += (size_t)batch * S * sizeof(oslamk_hit);
-    a->items = (uint32_t *)p;
-    p += (size_t)batch * nsl * S * 16;
-    a->item_sums = (unsigned long long *)p;
-    p += (size_t)batch * nsl * (S / 64 + 1) * sizeof(unsigned long long);
-    a->runs = (uint32_t *)p;
-    a->hit_count = pool->hit_count;
-    a->run_count = pool->hit_count + pool->hit_count_cap;
-    a->hit_stride = S;
+    size_t want = (slots ? slots : 1) * SLOT_BYTES;
+    if (p->bytes >= want) return OSLAM_OK;
+    if (p->buf) { (void)hipFree(p->buf); p->buf = NULL; p->bytes = 0; }
+    want += want / 8;                 /* head room: the next scene is rarely the same size */
+    if (want > scratch_limit() && slots * SLOT_BYTES <= scratch_limit()) want = scratch_limit();
+    if (hipMalloc((void **)&p->buf, want) != hipSuccess) {
+        (void)hipGetLastError();
+        p->buf = NULL;
+        want = (slots ? slots : 1) * SLOT_BYTES;
+        if (hipMalloc((void **)&p->buf, want) != hipSuccess) {
+            (void)hipGetLastError();
+            p->buf = NULL;
+            return fail(OSLAM_E_NOMEM, "no device memory for the hit lists");
+        }
+    }
+    p->bytes = want;
+    return OSLAM_OK;
 }
 
-#define MAX_BATCH_EVENTS 64
-
-static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
-                     float *ms_out, float *ms_vote_kernel, float *ms_key_kernel, uint32_t *launches)
+/* the arrays of a batch with `slots` places inside the pool */
+static void carve_scratch(oslamk_vote_args *a, const scratch_pool *p, size_t slots)
 {
-    int rc = OSLAM_OK, batch = 1, first, nb = 0, i;
-    hipEvent_t e0 = NULL, e1 = NULL, ev[3 * MAX_BATCH_EVENTS];
+    char *b = p->buf;
+    a->hit_pay = (oslamk_pay *)b;
+    b += slots * sizeof(oslamk_pay);
+    a->hit_sorted = (oslamk_pay *)b;
+    b += slots * sizeof(oslamk_pay);
+    a->runs = (oslamk_run *)b;
+    b += slots * sizeof(oslamk_run);
+    a->hit_key = (uint32_t *)b;
+}
+
+/* The batch that starts at reference point `first`: as many reference points as fit `limit_slots` places
+ * (at least one).  A list gets its count rounded up to even, so that every list starts 8-byte aligned in
+ * the 4-byte key array too.  off (may be NULL) receives the n + 1 offsets; *slots the batch total. */
+static int batch_extent(const uint32_t *keep, int first, int n_ref, size_t limit_slots, uint32_t *off, size_t *slots)
+{
+    size_t t = 0;
+    int n = 0;
+    while (first + n < n_ref) {
+        const size_t need = ((size_t)keep[first + n] + 1u) & ~(size_t)1u;
+        if (n > 0 && (t + need > limit_slots || t + need > 0xfffffff0u)) break;
+        if (off) off[n] = (uint32_t)t;
+        t += need;
+        n++;
+    }
+    if (off) off[n] = (uint32_t)t;
+    *slots = t;
+    return n;
+}
+
+/* The kernels of one registration (or of one reference point for the accumulator tap): count, then per
+ * batch scene keys -> hit sort -> votes.  d_ref_idx / d_tsg: the reference points and their frame rows.
+ * The caller holds the pool of the device. */
+static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, const uint32_t *d_ref_idx,
+                          const float *d_tsg, int n_ref, uint32_t fixed_gmax, uint32_t *acc_dump,
+                          oslamk_counters *cnt, float *ms_out, float *ms_vote_kernel, float *ms_key_kernel,
+                          uint32_t *launches, uint64_t *probed)
+{
+    int rc = OSLAM_OK, first, nb = 0, i;
     oslamk_vote_args a;
     hipStream_t st = (hipStream_t)g_stream;
-    scratch_pool *pool = NULL;
-    memset(ev, 0, sizeof ev);
-    rc = ensure_hit_scratch(m, s, &pool, &batch);
+    hipEvent_t *ev;
+    const size_t limit_slots = scratch_limit() / SLOT_BYTES;
+    size_t cap, max_batch_slots = 0;
+    uint32_t *h_keep, *h_off, *d_keep, *d_hitc, *d_runc, *d_off;
+    float k0 = 0.0f;
+    rc = pool_reserve_counts(pool, (size_t)(n_ref > 0 ? n_ref : 1));
     if (rc != OSLAM_OK) return rc;
+    ev = pool->ev;
+    cap = pool->counts_cap;
+    d_keep = pool->d_counts;
+    d_hitc = d_keep + cap;
+    d_runc = d_hitc + cap;
+    d_off = d_runc + cap;                       /* [2 * cap + 2] */
+    h_keep = pool->h_counts;
+    h_off = h_keep + cap;
     memset(&a, 0, sizeof a);
     a.scene = s->c.k;
-    a.ref_idx = s->d_ref_idx;
-    a.tsg = s->d_tsg;
-    a.n_ref = s->n_ref;
+    a.ref_idx = d_ref_idx;
+    a.tsg = d_tsg;
+    a.n_ref = n_ref;
     a.d_dist = m->d_dist;
     a.inv_d_dist = m->inv_d_dist;
     a.table = m->table;
@@ -891,87 +1041,147 @@ static int run_votes(oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk
     a.counters = m->d_counters;
     a.out = m->d_out;
     a.out_cap = m->out_cap;
-    a.acc_dump = NULL;
-    a.dump_ref = -1;
+    a.acc_dump = acc_dump;
+    a.dump_ref = acc_dump ? 0 : -1;
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
-    a.hits = pool->hits;
-    a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
-    a.hit_count = pool->hit_count;
-    a.hit_stride = (size_t)s->c.n;
-    carve_scratch(&a, pool, batch, (size_t)s->c.n, (size_t)m->table.n_slices);
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
-    HIPCHK(hipEventRecord(e0, st));
-    for (first = 0; first < s->n_ref; first += batch, nb++) {
-        const int timed = nb < MAX_BATCH_EVENTS;
-        a.first_ref = first;
-        a.n_launch = s->n_ref - first < batch ? s->n_ref - first : batch;
-        HIPCHK(hipMemsetAsync(pool->hit_count, 0, sizeof(uint32_t) * (size_t)a.n_launch, st));
-        if (timed) {
-            for (i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ev[3 * nb + i]));
-            HIPCHK(hipEventRecord(ev[3 * nb], st));
+    HIPCHK(hipEventRecord(ev[0], st));
+    /* 1. demand: pairs within reach, per reference point */
+    if (n_ref > 0) {
+        HIPCHK(hipMemsetAsync(d_keep, 0, sizeof(uint32_t) * (size_t)n_ref, st));
+        a.first_ref = 0;
+        a.n_launch = n_ref;
+        a.keep_count = d_keep;
+        KCHK(oslamk_scene_count(&a, g_stream));
+        HIPCHK(hipEventRecord(ev[2], st));
+        HIPCHK(hipMemcpyAsync(h_keep, d_keep, sizeof(uint32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventElapsedTime(&k0, ev[0], ev[2]));
+        if (ms_key_kernel) *ms_key_kernel += k0;
+        if (probed) {
+            uint64_t t = 0;
+            for (i = 0; i < n_ref; i++) t += h_keep[i];
+            *probed = t;
         }
-        KCHK(oslamk_scene_hits(&a, g_stream));
-        KCHK(oslamk_sort_hits(&a, g_stream));
-        if (timed) HIPCHK(hipEventRecord(ev[3 * nb + 1], st));
-        KCHK(oslamk_vote(&a, g_stream));
-        if (timed) HIPCHK(hipEventRecord(ev[3 * nb + 2], st));
-        if (launches) *launches += 1;
     }
-    HIPCHK(hipEventRecord(e1, st));
+    /* 2. batches that fit the pool; the offsets of every batch start at 0.  h_off holds, batch after
+     * batch, the n + 1 offsets of its n reference points */
+    {
+        size_t pos = 0;
+        for (first = 0; first < n_ref;) {
+            size_t slots;
+            const int n = batch_extent(h_keep, first, n_ref, limit_slots, h_off + pos, &slots);
+            if (slots > max_batch_slots) max_batch_slots = slots;
+            pos += (size_t)n + 1;
+            first += n;
+        }
+        rc = pool_reserve_slots(pool, max_batch_slots);
+        if (rc != OSLAM_OK) goto done;
+        if (pos) HIPCHK(hipMemcpyAsync(d_off, h_off, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, st));
+    }
+    /* 3. the batches */
+    {
+        size_t pos = 0;
+        for (first = 0; first < n_ref; nb++) {
+            const int timed = nb < MAX_BATCH_EVENTS;
+            size_t slots;
+            const int n = batch_extent(h_keep, first, n_ref, limit_slots, NULL, &slots);
+            a.first_ref = first;
+            a.n_launch = n;
+            a.keep_count = NULL;
+            a.hit_off = d_off + pos;
+            a.hit_count = d_hitc;
+            a.run_count = d_runc;
+            carve_scratch(&a, pool, slots);
+            HIPCHK(hipMemsetAsync(d_hitc, 0, sizeof(uint32_t) * (size_t)n, st));
+            if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb], st));
+            KCHK(oslamk_scene_hits(&a, g_stream));
+            KCHK(oslamk_sort_hits(&a, g_stream));
+            if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb + 1], st));
+            KCHK(oslamk_vote(&a, g_stream));
+            if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb + 2], st));
+            if (launches) *launches += 1;
+            pos += (size_t)n + 1;
+            first += n;
+        }
+    }
+    HIPCHK(hipEventRecord(ev[1], st));
     HIPCHK(hipMemcpyAsync(cnt, m->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, e0, e1));
+    if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, ev[0], ev[1]));
     for (i = 0; i < nb && i < MAX_BATCH_EVENTS; i++) {
         float k = 0.0f, v = 0.0f;
-        HIPCHK(hipEventElapsedTime(&k, ev[3 * i], ev[3 * i + 1]));
-        HIPCHK(hipEventElapsedTime(&v, ev[3 * i + 1], ev[3 * i + 2]));
+        HIPCHK(hipEventElapsedTime(&k, ev[4 + 3 * i], ev[4 + 3 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&v, ev[4 + 3 * i + 1], ev[4 + 3 * i + 2]));
         if (ms_key_kernel) *ms_key_kernel += k;
         if (ms_vote_kernel) *ms_vote_kernel += v;
     }
 done:
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    for (i = 0; i < 3 * MAX_BATCH_EVENTS; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+static int run_votes(scratch_pool *pool, oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
+                     float *ms_out, float *ms_vote_kernel, float *ms_key_kernel, uint32_t *launches, uint64_t *probed)
+{
+    return run_votes_refs(pool, m, s, s->d_ref_idx, s->d_tsg, s->n_ref, fixed_gmax, NULL, cnt, ms_out, ms_vote_kernel,
+                          ms_key_kernel, launches, probed);
+}
+
+/* record buffers (device and host) for at least `need` records; the contents are dropped */
+static int grow_records(oslam_model *m, uint64_t need)
+{
+    oslamk_cell *d_new = NULL;
+    oslam_cell *h_new;
+    if (need > ((uint64_t)1 << 28)) return fail(OSLAM_E_LIMIT, "more than 2^28 accumulator peaks above the threshold");
+    if (hipMalloc((void **)&d_new, sizeof(oslamk_cell) * need) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OSLAM_E_NOMEM, "no device memory for the accumulator peaks");
+    }
+    h_new = (oslam_cell *)malloc(sizeof(oslam_cell) * need);
+    if (!h_new) { (void)hipFree(d_new); return fail(OSLAM_E_NOMEM, "host allocation failed"); }
+    (void)hipFree(m->d_out);
+    free(m->h_out);
+    m->d_out = d_new;
+    m->h_out = h_new;
+    m->out_cap = (uint32_t)need;
+    m->n_local = 0;
+    return OSLAM_OK;
+}
+
+static int ensure_union(oslam_model *m, size_t n)
+{
+    if (m->union_cap >= n) return OSLAM_OK;
+    if (m->d_union) { (void)hipFree(m->d_union); m->d_union = NULL; m->union_cap = 0; }
+    if (hipMalloc((void **)&m->d_union, sizeof(oslamk_cell) * (n + n / 4)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OSLAM_E_NOMEM, "no device memory for the accumulator peaks");
+    }
+    m->union_cap = n + n / 4;
+    return OSLAM_OK;
 }
 
 /* vote + D2H of emitted cells; handles an overflowing record buffer by a second,
  * exactly thresholded launch */
-static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, size_t *n_cells,
+static int vote_and_fetch(scratch_pool *pool, oslam_model *m, oslam_scene *s, oslamk_counters *cnt, size_t *n_cells,
                           oslam_stats *st, size_t leave_on_device_from)
 {
     int rc = OSLAM_OK;
     float ms = 0.0f, ms2 = 0.0f, msv = 0.0f, msk = 0.0f;
     uint32_t launches = 0;
-    rc = run_votes(m, s, 0, cnt, &ms, &msv, &msk, &launches);
+    uint64_t probed = 0;
+    rc = run_votes(pool, m, s, 0, cnt, &ms, &msv, &msk, &launches, &probed);
     if (rc != OSLAM_OK) return rc;
     if (cnt->out_count > m->out_cap) {
         uint32_t g = cnt->gmax;
-        rc = run_votes(m, s, g, cnt, &ms2, &msv, &msk, &launches);
+        rc = run_votes(pool, m, s, g, cnt, &ms2, &msv, &msk, &launches, &probed);
         if (rc != OSLAM_OK) return rc;
         cnt->gmax = g;
         if (cnt->out_count > m->out_cap) {
             /* even the exactly thresholded set is larger than the record buffer: the count is known now, so
              * the buffers grow to it (up to 2^28 records = 4 GiB) and the launch is repeated */
-            const uint64_t need = (uint64_t)cnt->out_count + cnt->out_count / 8 + 1024;
-            oslamk_cell *d_new = NULL;
-            oslam_cell *h_new;
-            if (need > ((uint64_t)1 << 28))
-                return fail(OSLAM_E_LIMIT, "more than 2^28 accumulator peaks above the threshold");
-            if (hipMalloc((void **)&d_new, sizeof(oslamk_cell) * need) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(OSLAM_E_NOMEM, "no device memory for the accumulator peaks");
-            }
-            h_new = (oslam_cell *)malloc(sizeof(oslam_cell) * need);
-            if (!h_new) { (void)hipFree(d_new); return fail(OSLAM_E_NOMEM, "host allocation failed"); }
-            (void)hipFree(m->d_out);
-            free(m->h_out);
-            m->d_out = d_new;
-            m->h_out = h_new;
-            m->out_cap = (uint32_t)need;
-            rc = run_votes(m, s, g, cnt, &ms2, &msv, &msk, &launches);
+            rc = grow_records(m, (uint64_t)cnt->out_count + cnt->out_count / 8 + 1024);
+            if (rc != OSLAM_OK) return rc;
+            rc = run_votes(pool, m, s, g, cnt, &ms2, &msv, &msk, &launches, &probed);
             if (rc != OSLAM_OK) return rc;
             cnt->gmax = g;
             if (cnt->out_count > m->out_cap)
@@ -980,8 +1190,8 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
     }
     if (getenv("OSLAM_PROF"))      /* only a -DVOTE_PROF build fills these */
         fprintf(stderr, "[oslam prof] k_vote wave cycles: to the end of voting %llu, to the barrier after it %llu, "
-                        "peak extraction %llu, inside vote steps %llu\n",
-                cnt->prof[0], cnt->prof[1], cnt->prof[2], cnt->prof[3]);
+                        "peak extraction %llu\n",
+                cnt->prof[0], cnt->prof[1], cnt->prof[2]);
     *n_cells = cnt->out_count;
     /* the records stay in HBM when the pose tail runs there (leave_on_device_from = its lower bound, 0 = never) */
     if (*n_cells && !(leave_on_device_from && *n_cells >= leave_on_device_from)) {
@@ -999,10 +1209,15 @@ static int vote_and_fetch(oslam_model *m, oslam_scene *s, oslamk_counters *cnt, 
         st->ms_vote_kernel = msv;
         st->ms_key_kernel = msk;
         st->vote_launches = launches;
+        st->num_pairs_probed = probed;
+        st->scratch_bytes = pool->bytes;
     }
 done:
     return rc;
 }
+
+/* the pool the running call holds (the clustering hook below has no other way to reach it) */
+static __thread scratch_pool *g_cur_pool;
 
 /* clustering scores on the bound device (see oslam_pose.h); any failure makes the host loop run */
 static int cluster_scores_on_device(size_t n, const float *trans, const float *quat, const float *wv,
@@ -1028,7 +1243,16 @@ static int cluster_scores_on_device(size_t n, const float *trans, const float *q
         memcpy(h + o_st + 12 * j, trans + 3 * o, 12);
         ((float *)(h + o_sw))[j] = wv[o];
     }
-    HIPCHK(hipMalloc((void **)&d, total));
+    /* persistent workspace in the device's pool (the caller holds its lock) */
+    if (!g_cur_pool) { rc = OSLAM_E_DEVICE; goto done; }
+    if (g_cur_pool->cluster_bytes < total) {
+        if (g_cur_pool->d_cluster) (void)hipFree(g_cur_pool->d_cluster);
+        g_cur_pool->d_cluster = NULL;
+        g_cur_pool->cluster_bytes = 0;
+        HIPCHK(hipMalloc((void **)&g_cur_pool->d_cluster, total + total / 4));
+        g_cur_pool->cluster_bytes = total + total / 4;
+    }
+    d = g_cur_pool->d_cluster;
     HIPCHK(hipMemcpyAsync(d, h, o_sc, hipMemcpyHostToDevice, st));
     KCHK(oslamk_cluster_scores((int)n, (const float *)(d + o_tr), (const float *)(d + o_q), (const int *)(d + o_c),
                                (const uint32_t *)(d + o_sh), (const float *)(d + o_sq), (const float *)(d + o_st),
@@ -1037,7 +1261,6 @@ static int cluster_scores_on_device(size_t n, const float *trans, const float *q
     HIPCHK(hipStreamSynchronize(st));
 done:
     free(h);
-    if (d) (void)hipFree(d);
     return rc;
 }
 
@@ -1176,14 +1399,32 @@ static int finish_cells(oslam_model *m, oslam_scene *s, oslam_cell *cells, size_
 
 int oslam_align_prepare(oslam_model *m, oslam_scene *s)
 {
-    int rc, batch = 0;
-    scratch_pool *pool = NULL;
+    int rc;
+    scratch_pool *pool;
     rc = check_pair(m, s);
     if (rc != OSLAM_OK) return rc;
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
-    rc = ensure_hit_scratch(m, s, &pool, &batch);
-    if (rc != OSLAM_OK) return rc;
-    if (pose_gpu_from(m)) rc = pose_tables(m, s);
+    pool = pool_lock(m->dev);
+    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
+    rc = pool_reserve_counts(pool, (size_t)(s->n_ref > 0 ? s->n_ref : 1));
+    if (rc == OSLAM_OK && pose_gpu_from(m)) rc = pose_tables(m, s);
+    pool_unlock(pool);
+    return rc;
+}
+
+/* everything after the votes of one registration on one device: n records in m->d_out (and in m->h_out
+ * unless they were left on the device) */
+static int finish_after_votes(oslam_model *m, oslam_scene *s, size_t n, uint32_t gmax, float T[16], oslam_stats *stats)
+{
+    int rc = OSLAM_OK;
+    if (pose_gpu_from(m) && n >= pose_gpu_from(m)) {
+        int done = 0;
+        rc = finish_on_device(m, s, n, gmax, T, stats, &done);
+        if (rc != OSLAM_OK || done) return rc;
+        HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * n, hipMemcpyDeviceToHost));
+    }
+    rc = finish_cells(m, s, m->h_out, n, gmax, T, stats);
+done:
     return rc;
 }
 
@@ -1193,6 +1434,7 @@ int oslam_align(oslam_model *m, oslam_scene *s, float T[16], oslam_stats *stats)
     oslamk_counters cnt;
     size_t n = 0;
     oslam_stats local;
+    scratch_pool *pool;
     double t0 = now_ms();
     if (!T) return fail(OSLAM_E_INVALID, "T is NULL");
     memset(T, 0, 16 * sizeof(float));
@@ -1201,24 +1443,18 @@ int oslam_align(oslam_model *m, oslam_scene *s, float T[16], oslam_stats *stats)
     if (!stats) stats = &local;
     memset(stats, 0, sizeof *stats);
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
-    rc = vote_and_fetch(m, s, &cnt, &n, stats, pose_gpu_from(m));
-    if (rc != OSLAM_OK) return rc;
-    if (pose_gpu_from(m) && n >= pose_gpu_from(m)) {
-        int done = 0;
-        rc = finish_on_device(m, s, n, cnt.gmax, T, stats, &done);
-        if (rc != OSLAM_OK) return rc;
-        if (done) {
-            stats->ms_total = (float)(now_ms() - t0);
-            return OSLAM_OK;
-        }
-        HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * n, hipMemcpyDeviceToHost));
-    }
-    rc = finish_cells(m, s, m->h_out, n, cnt.gmax, T, stats);
+    pool = pool_lock(m->dev);
+    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
+    g_cur_pool = pool;
+    rc = vote_and_fetch(pool, m, s, &cnt, &n, stats, pose_gpu_from(m));
+    if (rc == OSLAM_OK) rc = finish_after_votes(m, s, n, cnt.gmax, T, stats);
+    g_cur_pool = NULL;
+    pool_unlock(pool);
     stats->ms_total = (float)(now_ms() - t0);
-done:
     return rc;
 }
 
+/* ---- multi-GPU, host-buffer form ------------------------------------------------------------- */
 int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, size_t cap,
                       size_t *n_out, uint32_t *local_max_out, oslam_stats *stats)
 {
@@ -1226,25 +1462,58 @@ int oslam_align_local(oslam_model *m, oslam_scene *s, oslam_cell *cells_out, siz
     oslamk_counters cnt;
     size_t n = 0;
     oslam_stats local;
+    scratch_pool *pool;
     double t0 = now_ms();
-    if (!cells_out || !n_out || !local_max_out) return fail(OSLAM_E_INVALID, "NULL output");
+    if (!n_out || !local_max_out || (!cells_out && cap)) return fail(OSLAM_E_INVALID, "NULL output");
+    *n_out = 0;
+    *local_max_out = 0;
     rc = check_pair(m, s);
     if (rc != OSLAM_OK) return rc;
     if (!stats) stats = &local;
     memset(stats, 0, sizeof *stats);
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
-    rc = vote_and_fetch(m, s, &cnt, &n, stats, 0);
+    pool = pool_lock(m->dev);
+    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
+    m->n_local = 0;
+    rc = vote_and_fetch(pool, m, s, &cnt, &n, stats, 0);
+    pool_unlock(pool);
     if (rc != OSLAM_OK) return rc;
-    /* peaks above the local threshold: a superset of what survives the global one */
+    /* peaks above the local threshold: a superset of what survives the global one; they stay with the
+     * model (oslam_local_peaks hands them out again, filtered with the global maximum) */
     n = oslam_filter_cells(m->h_out, n, m->params.vote_count_threshold, cnt.gmax);
-    if (n > cap) {            /* the strongest peaks are kept; cap is sized by the caller */
-        oslam_sort_cells(m->h_out, n);
-        n = cap;
-    }                         /* otherwise the order is left to oslam_align_finish, which orders the union */
-    memcpy(cells_out, m->h_out, sizeof(oslam_cell) * n);
+    m->n_local = n;
+    m->local_max = cnt.gmax;
     *n_out = n;
     *local_max_out = cnt.gmax;
     stats->ms_total = (float)(now_ms() - t0);
+    if (n > cap) {
+        /* nothing is dropped silently: the caller learns the count and either passes a larger buffer to
+         * oslam_local_peaks or exchanges the maxima first and asks for the (fewer) survivors */
+        if (cap) {
+            oslam_sort_cells(m->h_out, n);
+            memcpy(cells_out, m->h_out, sizeof(oslam_cell) * cap);
+        }
+        return cap ? fail(OSLAM_E_LIMIT, "more local peaks than the buffer holds: *n_out is the number; fetch them with oslam_local_peaks")
+                   : OSLAM_OK;
+    }
+    memcpy(cells_out, m->h_out, sizeof(oslam_cell) * n);
+    return OSLAM_OK;
+}
+
+int oslam_local_peaks(oslam_model *m, uint32_t global_max, oslam_cell *cells_out, size_t cap, size_t *n_out)
+{
+    size_t i, n = 0;
+    float bound;
+    if (!m || !n_out || (!cells_out && cap)) return fail(OSLAM_E_INVALID, "NULL argument");
+    if (global_max < m->local_max) return fail(OSLAM_E_INVALID, "the global maximum is below this rank's own");
+    bound = m->params.vote_count_threshold * (float)global_max;      /* model.cu:164 */
+    for (i = 0; i < m->n_local; i++)
+        if ((float)m->h_out[i].count > bound) {
+            if (n < cap) cells_out[n] = m->h_out[i];
+            n++;
+        }
+    *n_out = n;
+    if (n > cap) return fail(OSLAM_E_LIMIT, "more peaks above the global threshold than the buffer holds: *n_out is the number");
     return OSLAM_OK;
 }
 
@@ -1252,14 +1521,19 @@ int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, 
                        uint32_t global_max, float T[16], oslam_stats *stats)
 {
     int rc;
-    oslam_cell *tmp;
+    oslam_cell *tmp = NULL;
     oslam_stats local;
+    scratch_pool *pool;
     if (!T || (!cells && n)) return fail(OSLAM_E_INVALID, "NULL argument");
     memset(T, 0, 16 * sizeof(float));
     rc = check_pair(m, s);
     if (rc != OSLAM_OK) return rc;
     if (!stats) stats = &local;
+    memset(stats, 0, sizeof *stats);
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    pool = pool_lock(m->dev);
+    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
+    g_cur_pool = pool;
     if (pose_gpu_from(m) && n >= pose_gpu_from(m) && n <= m->out_cap) {
         /* the gathered union goes back to HBM; codes that do not name a reference point of this scene
          * and a point of this model are left to the host path, which reports them */
@@ -1272,15 +1546,173 @@ int oslam_align_finish(oslam_model *m, oslam_scene *s, const oslam_cell *cells, 
         if (ok) {
             HIPCHK(hipMemcpy(m->d_out, cells, sizeof(oslam_cell) * n, hipMemcpyHostToDevice));
             rc = finish_on_device(m, s, n, global_max, T, stats, &done);
-            if (rc != OSLAM_OK || done) return rc;
+            if (rc != OSLAM_OK || done) goto done;
         }
     }
     tmp = (oslam_cell *)malloc(sizeof(oslam_cell) * (n ? n : 1));
-    if (!tmp) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    if (!tmp) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
     memcpy(tmp, cells, sizeof(oslam_cell) * n);
     rc = finish_cells(m, s, tmp, n, global_max, T, stats);
-    free(tmp);
 done:
+    free(tmp);
+    g_cur_pool = NULL;
+    pool_unlock(pool);
+    return rc;
+}
+
+/* ---- multi-GPU over RCCL: one call per rank does everything (ppf.h:9-15 is one call too) -------
+ * The exchange stays in HBM: all-reduce(MAX) of the vote maxima, the local records filtered with the
+ * global threshold where they lie, an all-gather of the survivor counts, one broadcast per rank of its
+ * survivors straight into the union buffer (grouped: an all-gather with exact sizes), and the pose
+ * tail on the union -- on the device when it is large.  Collectives run on the stream of
+ * oslam_set_stream.  Latency-bound: a few KiB to a few hundred KiB per rank over xGMI. */
+struct oslam_comm {
+    ncclComm_t nccl;
+    int rank, world, dev;
+    uint32_t *d_small;                 /* [2 + world]: maximum, count, counts of all ranks */
+    uint32_t *h_small;
+};
+
+static int nccl_fail(ncclResult_t r, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, ncclGetErrorString(r));
+    return OSLAM_E_DEVICE;
+}
+
+#define NCCLCHK(call)                                  \
+    do {                                               \
+        ncclResult_t r_ = (call);                      \
+        if (r_ != ncclSuccess) {                       \
+            rc = nccl_fail(r_, #call);                 \
+            goto done;                                 \
+        }                                              \
+    } while (0)
+
+int oslam_comm_unique_id(void *id_out)
+{
+    ncclUniqueId id;
+    ncclResult_t r;
+    if (!id_out) return fail(OSLAM_E_INVALID, "id_out is NULL");
+    r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId");
+    memcpy(id_out, &id, OSLAM_COMM_ID_BYTES);
+    return OSLAM_OK;
+}
+
+void oslam_comm_destroy(oslam_comm *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (c->d_small) (void)hipFree(c->d_small);
+    free(c->h_small);
+    free(c);
+}
+
+int oslam_comm_create(const void *id, int rank, int world, int dev, oslam_comm **out)
+{
+    int rc = OSLAM_OK;
+    oslam_comm *c;
+    ncclUniqueId uid;
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(OSLAM_E_INVALID, "bad communicator arguments");
+    if (sizeof(ncclUniqueId) != OSLAM_COMM_ID_BYTES) return fail(OSLAM_E_DEVICE, "ncclUniqueId is not 128 bytes in this RCCL");
+    c = (oslam_comm *)calloc(1, sizeof *c);
+    if (!c) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    c->rank = rank;
+    c->world = world;
+    rc = pick_device(dev, &c->dev);
+    if (rc != OSLAM_OK) goto done;
+    memcpy(&uid, id, sizeof uid);
+    NCCLCHK(ncclCommInitRank(&c->nccl, world, uid, rank));
+    HIPCHK(hipMalloc((void **)&c->d_small, sizeof(uint32_t) * (size_t)(2 + world)));
+    c->h_small = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(2 + world));
+    if (!c->h_small) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+done:
+    if (rc != OSLAM_OK) { oslam_comm_destroy(c); return rc; }
+    *out = c;
+    return OSLAM_OK;
+}
+
+int oslam_align_multi(oslam_model *m, oslam_scene *s, oslam_comm *c, float T[16], oslam_stats *stats)
+{
+    int rc, r;
+    oslamk_counters cnt;
+    size_t n = 0, total = 0;
+    uint32_t gmax, n_mine = 0;
+    oslam_stats local;
+    scratch_pool *pool = NULL;
+    hipStream_t st = (hipStream_t)g_stream;
+    double t0 = now_ms();
+    if (!T || !c) return fail(OSLAM_E_INVALID, "NULL argument");
+    memset(T, 0, 16 * sizeof(float));
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (c->dev != m->dev) return fail(OSLAM_E_INVALID, "communicator and model live on different devices");
+    if (s->world != c->world || s->rank != c->rank) return fail(OSLAM_E_INVALID, "the scene's shard differs from the communicator's rank");
+    if (!stats) stats = &local;
+    memset(stats, 0, sizeof *stats);
+    if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    pool = pool_lock(m->dev);
+    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
+    g_cur_pool = pool;
+    /* this rank's votes; the records stay in m->d_out */
+    rc = vote_and_fetch(pool, m, s, &cnt, &n, stats, 1);
+    if (rc != OSLAM_OK) goto done;
+    /* the threshold is global (model.cu:164-170): maximum over ranks */
+    c->h_small[0] = cnt.gmax;
+    HIPCHK(hipMemcpyAsync(c->d_small, c->h_small, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    NCCLCHK(ncclAllReduce(c->d_small, c->d_small, 1, ncclUint32, ncclMax, c->nccl, st));
+    HIPCHK(hipMemcpyAsync(&gmax, c->d_small, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    /* survivors of this rank, compacted into the second record buffer */
+    rc = ensure_union(m, n > 0 ? n : 1);
+    if (rc != OSLAM_OK) goto done;
+    if (n) {
+        const int k = oslamk_select_cells(m->d_out, (uint32_t)n, m->params.vote_count_threshold * (float)gmax, m->d_union,
+                                          &n_mine, g_stream);
+        if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
+    }
+    c->h_small[1] = n_mine;
+    HIPCHK(hipMemcpyAsync(c->d_small + 1, c->h_small + 1, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    NCCLCHK(ncclAllGather(c->d_small + 1, c->d_small + 2, 1, ncclUint32, c->nccl, st));
+    HIPCHK(hipMemcpyAsync(c->h_small + 2, c->d_small + 2, sizeof(uint32_t) * (size_t)c->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (r = 0; r < c->world; r++) total += c->h_small[2 + r];
+    if (total > ((size_t)1 << 28)) { rc = fail(OSLAM_E_LIMIT, "more than 2^28 accumulator peaks above the threshold"); goto done; }
+    /* the union, rank after rank, in m->d_out (grown if needed; this rank's survivors are safe in d_union) */
+    if (total > m->out_cap) {
+        rc = grow_records(m, total + total / 8 + 1024);
+        if (rc != OSLAM_OK) goto done;
+    }
+    if (total) {
+        size_t off = 0;
+        NCCLCHK(ncclGroupStart());
+        for (r = 0; r < c->world; r++) {
+            const size_t nr = c->h_small[2 + r];
+            if (nr) {
+                ncclResult_t br = ncclBroadcast(m->d_union, m->d_out + off, nr * sizeof(oslamk_cell), ncclUint8, r, c->nccl, st);
+                if (br != ncclSuccess) { (void)ncclGroupEnd(); rc = nccl_fail(br, "ncclBroadcast"); goto done; }
+            }
+            off += nr;
+        }
+        NCCLCHK(ncclGroupEnd());
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    stats->num_emitted = (uint32_t)total;
+    /* every rank finishes on the same union: same pose everywhere, no second exchange */
+    if (pose_gpu_from(m) && total >= pose_gpu_from(m)) {
+        int done = 0;
+        rc = finish_on_device(m, s, total, gmax, T, stats, &done);
+        if (rc != OSLAM_OK || done) goto done;
+    }
+    if (total) HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * total, hipMemcpyDeviceToHost));
+    rc = finish_cells(m, s, m->h_out, total, gmax, T, stats);
+done:
+    g_cur_pool = NULL;
+    pool_unlock(pool);
+    stats->ms_total = (float)(now_ms() - t0);
     return rc;
 }
 
@@ -1442,7 +1874,8 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
     float *d_tsg = NULL;
     float rows[8];
     uint32_t ref = (uint32_t)ref_index;
-    oslamk_vote_args a;
+    oslamk_counters cnt;
+    scratch_pool *pool = NULL;
     size_t cells;
     rc = check_pair(m, s);
     if (rc != OSLAM_OK) return rc;
@@ -1450,52 +1883,22 @@ int oslam_vote_accumulator(oslam_model *m, oslam_scene *s, size_t ref_index, uin
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
     cells = (size_t)m->table.n_slices * OSLAMK_SLICE * OSLAMK_NBIN;
     oslam_T_g_rows(s->c.h_xyz, s->c.h_nrm, &ref, 1, rows);
+    pool = pool_lock(m->dev);
+    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
     HIPCHK(hipMalloc((void **)&d_dump, sizeof(uint32_t) * cells));
     HIPCHK(hipMalloc((void **)&d_ref, sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **)&d_tsg, sizeof rows));
     HIPCHK(hipMemcpy(d_ref, &ref, sizeof ref, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_tsg, rows, sizeof rows, hipMemcpyHostToDevice));
-    memset(&a, 0, sizeof a);
-    a.scene = s->c.k;
-    a.ref_idx = d_ref;
-    a.tsg = d_tsg;
-    a.n_ref = 1;
-    a.d_dist = m->d_dist;
-    a.inv_d_dist = m->inv_d_dist;
-    a.table = m->table;
-    a.ent = m->ent;
-    a.thresh = m->params.vote_count_threshold;
-    a.fixed_gmax = 0xffffffffu;                /* emit nothing */
-    a.counters = m->d_counters;
-    a.out = m->d_out;
-    a.out_cap = m->out_cap;
-    a.acc_dump = d_dump;
-    a.dump_ref = 0;
-    a.first_ref = 0;
-    a.n_launch = 1;
-    a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
-    {
-        int batch = 1;
-        scratch_pool *pool = NULL;
-        rc = ensure_hit_scratch(m, s, &pool, &batch);
-        if (rc != OSLAM_OK) goto done;
-        a.hits = pool->hits;
-        a.hits_sorted = pool->hits + (size_t)batch * (size_t)s->c.n;
-        a.hit_count = pool->hit_count;
-        carve_scratch(&a, pool, batch, (size_t)s->c.n, (size_t)m->table.n_slices);
-    }
-    a.hit_stride = (size_t)s->c.n;
-    HIPCHK(hipMemsetAsync(a.hit_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));
-    KCHK(oslamk_scene_hits(&a, g_stream));
-    KCHK(oslamk_sort_hits(&a, g_stream));
-    HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), (hipStream_t)g_stream));
-    KCHK(oslamk_vote(&a, g_stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    /* one reference point through the same kernels; fixed_gmax = all ones: nothing is emitted */
+    rc = run_votes_refs(pool, m, s, d_ref, d_tsg, 1, 0xffffffffu, d_dump, &cnt, NULL, NULL, NULL, NULL, NULL);
+    if (rc != OSLAM_OK) goto done;
     h_dump = (uint32_t *)malloc(sizeof(uint32_t) * cells);
     if (!h_dump) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
     HIPCHK(hipMemcpy(h_dump, d_dump, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
     memcpy(acc_out, h_dump, sizeof(uint32_t) * OSLAMK_NBIN * (size_t)m->c.n);
 done:
+    pool_unlock(pool);
     free(h_dump);
     if (d_dump) (void)hipFree(d_dump);
     if (d_ref) (void)hipFree(d_ref);

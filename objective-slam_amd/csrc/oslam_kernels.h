@@ -48,8 +48,15 @@ typedef struct oslamk_cloud {
     int n;
 } oslamk_cloud;
 
+/* Bucket of one key in one slice, addressed directly by the key's slot in the union table:
+ * what a vote workgroup reads instead of probing (the scene-key kernel already found the slot). */
+typedef struct oslamk_uinfo {
+    uint32_t start;            /* first entry of the bucket */
+    uint32_t len;              /* bucket length (0 = the slice has no pair with this key); bit 31: the bucket holds a marker entry */
+} oslamk_uinfo;
+
 typedef struct oslamk_table {
-    oslamk_slot *slots;        /* [n_slices][cap] */
+    oslamk_slot *slots;        /* [n_slices][cap]: the build's counting tables (kept for the taps and the file) */
     uint32_t cap;              /* power of two */
     uint32_t shift;            /* 32 - log2(cap) */
     int n_slices;
@@ -59,6 +66,7 @@ typedef struct oslamk_table {
     /* reach[k1 / 32] bit k1 % 32: some key of the model can come from a pair in distance bin k1
      * (FNV collisions included), k1 < OSLAMK_REACH_BINS; pairs in other bins cannot hit */
     uint32_t *reach;
+    oslamk_uinfo *uinfo;       /* [n_slices][ucap] */
 } oslamk_table;
 
 #define OSLAMK_REACH_BINS 16384
@@ -102,9 +110,20 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
  * together carry evenly spaced theta_u (fewer bank conflicts of the vote atomics) */
 int oslamk_bucket_spread(oslamk_table t, oslamk_entries ent, void *stream);
 
-typedef struct oslamk_hit {
-    uint32_t key, vy_bits, vz_bits, theta_t22;
-} oslamk_hit;
+/* A scene pair whose key is in the model ("hit"): what a vote needs of it.  The rows y,z of
+ * T_s_g * s_i (kernel.cu:334-336) that the rare exact re-evaluation needs are recomputed from the
+ * scene index. */
+typedef struct oslamk_pay {
+    uint32_t theta_t22;        /* pc_angle_t22 of (T_s_g * s_i).y/.z */
+    uint32_t idx;              /* scene index of s_i */
+} oslamk_pay;
+
+/* A run of hits of one reference point that share a key (at most 64 of them). */
+typedef struct oslamk_run {
+    uint32_t slot_r;           /* union-table slot of the key | (hits - 1) << OSLAMK_RUN_SHIFT */
+    uint32_t first;            /* first hit of the run in the reference point's sorted hit list */
+} oslamk_run;
+#define OSLAMK_RUN_SHIFT 26    /* union tables have at most 2^26 slots */
 
 typedef struct oslamk_vote_args {
     oslamk_cloud scene;
@@ -124,23 +143,27 @@ typedef struct oslamk_vote_args {
     int first_ref;             /* launch covers reference ordinals first_ref .. first_ref+n_launch-1 */
     int n_launch;
     int mode;                  /* 0 exact (near-edge votes re-evaluated), 1 fast (never) */
-    /* per-reference hit lists of this batch (written by oslamk_scene_hits, read by oslamk_vote):
-     * hits[ref_local * hit_stride + k] = {key, vy bits, vz bits, theta_v}, k < hit_count[ref_local] */
-    oslamk_hit *hits;
-    oslamk_hit *hits_sorted;   /* the same lists sorted by key (oslamk_sort_hits) -- what oslamk_vote reads */
-    uint32_t *hit_count;
-    size_t hit_stride;
-    /* run lists (written by oslamk_sort_hits): runs[ref_local * (hit_stride + 1) + u] = {key, first hit
-     * of the run in hits_sorted}, u <= run_count[ref_local]; the last one is the end marker {0, hit_count} */
-    uint32_t *runs;
-    uint32_t *run_count;
-    /* scratch of the vote workgroups, one region per (ref_local, slice) = per workgroup:
-     * items[wg * hit_stride + k] = {bucket start, length | marker << 31, first hit, hits} (16 B) and
-     * item_sums[wg * (hit_stride / 64 + 1) + k / 64] = work units before item k, for k % 64 == 0 */
-    uint32_t *items;
-    unsigned long long *item_sums;
+    /* Hit lists of the batch, sized by demand: reference point ref_local owns the slots
+     * hit_off[ref_local] .. hit_off[ref_local + 1] of every array below; the size is the number of its
+     * scene pairs whose distance bin can reach a model key (oslamk_scene_count), an upper bound of its hits.
+     *   hit_key / hit_pay : hits in arrival order (oslamk_scene_hits): union-table slot of the key, payload
+     *   hit_sorted        : the payloads ordered by slot (oslamk_sort_hits) -- what oslamk_vote reads
+     *   runs              : runs of equal keys in hit_sorted, run_count[ref_local] of them */
+    uint32_t *keep_count;      /* [n_launch] written by oslamk_scene_count (must be zero on entry) */
+    const uint32_t *hit_off;   /* [n_launch + 1] */
+    uint32_t *hit_key;
+    oslamk_pay *hit_pay;
+    oslamk_pay *hit_sorted;
+    oslamk_run *runs;
+    uint32_t *hit_count;       /* [n_launch] */
+    uint32_t *run_count;       /* [n_launch] */
 } oslamk_vote_args;
 
+/* fill t.uinfo from the slice tables (after oslamk_table_scan / oslamk_union_build and the fill pass) */
+int oslamk_uinfo_build(oslamk_table t, void *stream);
+
+/* keep_count[ref_local] += scene pairs of the reference point whose distance bin can reach a model key */
+int oslamk_scene_count(const oslamk_vote_args *a, void *stream);
 /* scene pair keys -> per-reference hit lists, for reference ordinals first_ref..+n_launch-1;
  * hit_count[0..n_launch) must be zero on entry */
 int oslamk_scene_hits(const oslamk_vote_args *a, void *stream);
@@ -176,6 +199,12 @@ int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, float min_vo
                       const float *d_Ts16, uint32_t df, const float *d_weights, const float *h_rotx_cs, float d_dist,
                       int use_l1, oslamk_cell *d_cells_out, float *d_poses, uint32_t *n_out, uint32_t *best_out,
                       float T_best[16], void *stream);
+
+/* records with count > min_votecount, compacted into d_out (capacity n_in); *n_out on the host */
+int oslamk_select_cells(const oslamk_cell *d_in, uint32_t n_in, float min_votecount, oslamk_cell *d_out, uint32_t *n_out,
+                        void *stream);
+/* frees the pose tail's work space on the current device */
+void oslamk_pose_release(void);
 
 /* device self-test: out_acos[i] = pm_acosf(x[i]); out_atan2[i] = pm_atan2f(y[i], x2[i]);
  * out_bin[i] = pc_alpha_bin_exact(...) */

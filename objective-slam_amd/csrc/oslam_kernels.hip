@@ -7,22 +7,26 @@
  * (pcl/alignment/src/cuda/{scene,model}.cu) is fused here:
  *   model build : pair key -> per-slice open-addressing table -> bucketed
  *                 4-byte pair entries (two counting passes, no sort); union table
- *                 of all keys; bitset of the distance bins that can reach a key;
- *                 entries ordered inside each bucket for the LDS banks;
+ *                 of all keys, and per slice the bucket of every union slot; bitset
+ *                 of the distance bins that can reach a key; entries ordered inside
+ *                 each bucket for the LDS banks;
+ *   scene count : per reference point, the pairs whose distance bin can reach a
+ *                 model key: sizes the hit lists by demand;
  *   scene keys  : per (reference r, tile of scene points): distance bin of every
  *                 pair, unreachable bins dropped, the rest compacted in LDS; full
  *                 key -> union-table probe -> per-reference hit list
- *                 {key, T_s_g*s_i, theta_v} written by wave-aggregated appends;
- *   hit sort    : per reference point, hits ordered by key (LDS radix sort) and
- *                 the list of runs of equal keys;
- *   voting      : one workgroup per (scene reference point, model slice): runs ->
- *                 slice table probes -> items (bucket, hits) in scratch; the work
- *                 in units of (chunk of 256 entries, hit), handed to the 16 waves
- *                 in grains; a wave streams a bucket once for all hits that share
- *                 it (16 bytes = 4 entries per lane, loads two steps ahead) ->
- *                 integer alpha bin -> LDS accumulator [1024 model refs][32 alpha
- *                 bins]; votes near a bin edge queued and re-evaluated with the
- *                 reference's float sequence; in-kernel peak extraction;
+ *                 {union slot} + {theta_v, i} written by wave-aggregated appends;
+ *   hit sort    : per reference point, hits ordered by union slot (LDS radix
+ *                 sort) and the list of runs of equal keys;
+ *   voting      : one workgroup per (scene reference point, model slice): a run
+ *                 finds its bucket with one load (no probing); very long items are
+ *                 cut into units dealt to the 16 waves, the rest is handed out
+ *                 dynamically a few runs at a time; a wave streams a bucket once
+ *                 for all hits that share it (16 bytes = 4 entries per lane, next
+ *                 step's loads in flight) -> integer alpha bin -> LDS accumulator
+ *                 [1024 model refs][32 alpha bins]; votes near a bin edge queued
+ *                 and re-evaluated with the reference's float sequence; in-kernel
+ *                 peak extraction;
  *   clustering  : scores of the candidate poses (one wave per pose).
  */
 #include <hip/hip_runtime.h>
@@ -35,16 +39,7 @@
 #include "ppf_core.h"
 
 #define WAVE 64
-#ifndef VOTE_PIPE
-#define VOTE_PIPE 2       /* steps whose loads are in flight ahead of the one being voted */
-#endif
 #define VOTE_THREADS 1024
-#ifndef VOTE_GRAINS
-#define VOTE_GRAINS 64       /* pieces the units of a workgroup are handed out in (16 waves) */
-#endif
-#ifndef VOTE_STEP_COST
-#define VOTE_STEP_COST 4     /* what a step (chunk load, set-up) costs, in units of one hit's votes: for the work split */
-#endif
 #define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
 
 /* thresholds of pc_alpha_bin_table(); every vote workgroup copies them into LDS */
@@ -186,6 +181,30 @@ __global__ __launch_bounds__(256) void k_reach_build(oslamk_table t, float d_dis
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_found) atomicOr(&t.reach[k1 >> 5], 1u << (k1 & 31u));
+}
+
+/* table.uinfo[slice][slot of the key in the union table] = the key's bucket in that slice: lets the vote
+ * kernel go from a hit to its bucket with one load instead of a probe sequence.  One thread per slot of
+ * the slice tables; uinfo is zeroed by the host (len 0 = the slice has no pair with that key). */
+__global__ void k_uinfo_build(oslamk_table t)
+{
+    const size_t total = (size_t)t.n_slices * t.cap;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const oslamk_slot sl = t.slots[idx];
+    if (sl.key == 0) return;
+    const uint32_t mask = t.ucap - 1;
+    uint32_t slot = slot_of(sl.key, t.ushift);
+    for (uint32_t probe = 0; probe <= mask; probe++) {
+        if (t.ukeys[slot] == sl.key) {
+            oslamk_uinfo ui;
+            ui.start = sl.start;
+            ui.len = sl.len | (sl.cur & 0x80000000u);      /* bit 31 of the fill cursor: marker entry in the bucket */
+            t.uinfo[(idx / t.cap) * (size_t)t.ucap + slot] = ui;
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
 }
 
 /* pass 2: same pairs, written into their buckets */
@@ -370,6 +389,16 @@ __device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
 #define ACC_TRASH ACC_CELLS            /* 64 + 32 words: lane's word + bin */
 #define ACC_TRASH_WORDS 96
 
+/* what the re-evaluation of a vote reads besides the entry: the reference point's hit list, the
+ * scene cloud and the rows y,z of T_s_g (kernel.cu:334-336) */
+struct SlowCtx {
+    const uint32_t *e4;
+    const oslamk_uv *uv;
+    const oslamk_pay *hits;
+    const float *px, *py, *pz;
+    const float *rows;
+};
+
 /* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index, hit index};
  * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
  * a time by flush(). */
@@ -385,71 +414,67 @@ struct SlowQueue {
         }
         n += (uint32_t)__popcll(mask);
     }
-    __device__ __forceinline__ void flush(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                          const uint32_t *tbl, int lane);
+    __device__ __forceinline__ void flush(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, int lane);
 };
 
-/* LDS pointers of the out-of-line flush */
+/* LDS pointers of the out-of-line flush; its context lives in LDS too (a kernel's stack would be scratch memory) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+typedef __attribute__((address_space(3))) const SlowCtx lds_ctx;
 
 /* Out of line on purpose: inlined, its loads make the compiler wait for the prefetched chunk at the
  * top of the vote loop (it cannot tell the two apart at the loop head); a call site settles that. */
-__device__ __noinline__ void slow_queue_flush(const uint32_t *e4, const oslamk_uv *uvs, const uint4 *hits,
-                                              lds_u32 *acc, lds_u32 *tbl, lds_cu64 *q, uint32_t n, int lane)
+__device__ __noinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_cu64 *q, uint32_t n, int lane)
 {
     const uint32_t *t = (const uint32_t *)tbl;
     for (uint32_t base = 0; base < n; base += WAVE) {
         if (base + lane < n) {
             const unsigned long long it = q[base + lane];
             const uint32_t entry = (uint32_t)it;
-            const uint32_t mr = e4[entry] >> 22;
-            const float2 uv = *reinterpret_cast<const float2 *>(&uvs[entry]);
-            const uint4 h = hits[(uint32_t)(it >> 32)];
-            const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, __builtin_bit_cast(float, h.y),
-                                                    __builtin_bit_cast(float, h.z), t);
+            const uint32_t mr = sc->e4[entry] >> 22;
+            const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
+            const uint32_t i = sc->hits[(uint32_t)(it >> 32)].idx;
+            const float x = sc->px[i], y = sc->py[i], z = sc->pz[i];
+            const float vy = pc_row_dot(sc->rows, x, y, z);        /* as k_scene_hits computed them */
+            const float vz = pc_row_dot(sc->rows + 4, x, y, z);
+            const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
             if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[(mr << 5) + bin], 1u);
         }
     }
 }
 
-__device__ __forceinline__ void SlowQueue::flush(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                                 const uint32_t *tbl, int lane)
+__device__ __forceinline__ void SlowQueue::flush(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, int lane)
 {
-    if (n)
-        slow_queue_flush(a.ent.e4, a.ent.uv, hits, (lds_u32 *)acc, (lds_u32 *)tbl, (lds_cu64 *)q, n, lane);
+    if (n) slow_queue_flush((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)tbl, (lds_cu64 *)q, n, lane);
     n = 0;
 }
 
 /* One step of a wave (all fields wave-uniform): one chunk of a bucket voted by the hits
- * i0 .. i1-1 of the run piece (at most 64 hits, one per lane). */
+ * i0 .. i1-1 of a run (at most 64 hits, one per lane). */
 struct VoteStep {
-    const uint32_t *chunk;             /* first entry of the chunk */
-    const uint4 *hit0;                 /* first hit of the run piece */
+    uint32_t e0;                       /* index of the chunk's first entry */
     uint32_t left;                     /* entries from the chunk start to the bucket end (>= 1) */
-    uint32_t entry0;                   /* index of the chunk's first entry (for the re-evaluation queue) */
-    uint32_t hbase;                    /* index of the piece's first hit (same) */
-    uint32_t R;
-    int i0, i1;
+    uint32_t h0;                       /* index of the run's first hit in the reference point's sorted list */
+    uint32_t R;                        /* hits of the run */
+    int i0, i1;                        /* the hits of the run that vote in this step */
     bool bforced, valid;               /* bforced: the bucket holds an entry with the marker */
 };
 
 template <int MODE>
 struct VoteRegs {
     uint4 v;                           /* 4 entries of the chunk: lane l holds entries 4l .. 4l+3 */
-    uint32_t th;                       /* theta_v of hit `lane` of the piece */
-    __device__ __forceinline__ void load(const VoteStep &d, int lane)
+    uint32_t th;                       /* theta_v of hit `lane` of the run */
+    __device__ __forceinline__ void load(const uint32_t *e4, const oslamk_pay *hits, const VoteStep &d, int lane)
     {
-        if (4u * (uint32_t)lane < d.left) v = reinterpret_cast<const uint4 *>(d.chunk)[lane];
-        if ((uint32_t)lane < d.R) th = d.hit0[lane].w;
+        if (4u * (uint32_t)lane < d.left) v = reinterpret_cast<const uint4 *>(e4 + d.e0)[lane];
+        if ((uint32_t)lane < d.R) th = hits[d.h0 + (uint32_t)lane].theta_t22;
     }
     /* Votes of hit i that are near a bin edge (or all of them: forced) are queued for re-evaluation
      * and their lanes redirected to the trash word. */
-    __device__ __forceinline__ static void queue_edge_votes(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                                            const uint32_t *tbl, SlowQueue &sq, uint32_t entry0,
-                                                            uint32_t hit, uint32_t left, bool forced,
-                                                            const uint32_t (&pos)[4], uint32_t (&addr)[4], int lane,
-                                                            uint32_t trash_addr)
+    __device__ __forceinline__ static void queue_edge_votes(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl,
+                                                            SlowQueue &sq, uint32_t entry0, uint32_t hit, uint32_t left,
+                                                            bool forced, const uint32_t (&pos)[4], uint32_t (&addr)[4],
+                                                            int lane, uint32_t trash_addr)
     {
         uint32_t e = 4u * (uint32_t)lane;
         asm volatile("" : "+v"(e));      /* keeps the compares below out of the vote loop's preamble */
@@ -457,20 +482,19 @@ struct VoteRegs {
         for (int j = 0; j < 4; j++) {
             const unsigned long long nm = __ballot(e + j < left && (forced || pos[j] < PC_T24_EDGE));
             if (nm) {
-                if (sq.n > SlowQueue::CAP - WAVE) sq.flush(a, hits, acc, tbl, lane);
+                if (sq.n > SlowQueue::CAP - WAVE) sq.flush(sc, acc, tbl, lane);
                 sq.push(nm, lane, entry0 + e + j, hit);
                 if ((nm >> lane) & 1ull) addr[j] = trash_addr;
             }
         }
     }
     /* FULL: all 256 entries of the chunk exist, no lane needs the trash word.  FORCED: some hit of the
-     * piece (or the whole bucket) carries the marker and has every vote re-evaluated; the common
+     * run (or the whole bucket) carries the marker and has every vote re-evaluated; the common
      * variant has no trace of that in its loop: readlane + 19 vector + compare/branch + 4 LDS atomics
      * + loop control per hit (256 votes). */
     template <bool FULL, bool FORCED>
-    __device__ __forceinline__ void vote_impl(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                              const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane,
-                                              unsigned long long fmask) const
+    __device__ __forceinline__ void vote_impl(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, SlowQueue &sq,
+                                              const VoteStep &d, int lane, unsigned long long fmask) const
     {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t24(th) << 8;     /* see vote_product */
@@ -503,7 +527,7 @@ struct VoteRegs {
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
                 const bool forced = FORCED && ((fmask >> i) & 1ull);
                 if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
-                    queue_edge_votes(a, hits, acc, tbl, sq, d.entry0, d.hbase + (uint32_t)i, d.left, forced, pos, addr, lane, trash_addr);
+                    queue_edge_votes(sc, acc, tbl, sq, d.e0, d.h0 + (uint32_t)i, d.left, forced, pos, addr, lane, trash_addr);
             }
             if (FULL) {
 #pragma unroll
@@ -528,35 +552,90 @@ struct VoteRegs {
                              : "memory");
             }
         };
-        /* the step's range is in padded units (VOTE_STEP_COST after the hits): only the hits vote */
-        const int i_end = d.i1 < (int)d.R ? d.i1 : (int)d.R;
-        for (int i = d.i0; i < i_end; i++) one_hit(i);
+        for (int i = d.i0; i < d.i1; i++) one_hit(i);
     }
-    __device__ __forceinline__ void vote(const oslamk_vote_args &a, const uint4 *hits, uint32_t *acc,
-                                         const uint32_t *tbl, SlowQueue &sq, const VoteStep &d, int lane) const
+    __device__ __forceinline__ void vote(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, SlowQueue &sq,
+                                         const VoteStep &d, int lane) const
     {
         /* hits whose every vote is re-evaluated: all of them when the bucket holds a marker */
         const unsigned long long fmask =
             MODE == 0 ? (d.bforced ? ~0ull : __ballot(th == PC_T22_FORCE) & ((2ull << (d.R - 1u)) - 1ull)) : 0ull;
-        if (MODE == 0 && fmask) vote_impl<false, true>(a, hits, acc, tbl, sq, d, lane, fmask);
-        else if (d.left >= 4u * WAVE) vote_impl<true, false>(a, hits, acc, tbl, sq, d, lane, 0ull);
-        else vote_impl<false, false>(a, hits, acc, tbl, sq, d, lane, 0ull);
+        if (MODE == 0 && fmask) vote_impl<false, true>(sc, acc, tbl, sq, d, lane, fmask);
+        else if (d.left >= 4u * WAVE) vote_impl<true, false>(sc, acc, tbl, sq, d, lane, 0ull);
+        else vote_impl<false, false>(sc, acc, tbl, sq, d, lane, 0ull);
     }
 };
 
-/* Scene::Scene's key pass (scene.cu:24-55: K1 ppf_kernel + K2 ppf_hash_kernel) fused with
- * the lookup of model.cu:96-97, for the pairs (reference point r, point i) of one tile of
- * KEY_TILE scene points.  Phase 1 (cheap, every pair): distance bin only; pairs whose bin
- * cannot produce a model key (table.reach: exact, FNV collisions included) are dropped, the
- * rest are compacted into LDS.  Phase 2 (dense lanes): full key, union-table probe, and pairs
- * that hit are appended to r's hit list as {key, (T_s_g*s_i).y, (T_s_g*s_i).z, theta_v}; one
- * atomic per wave reserves the slots.  grid (ceil(S/KEY_TILE), refs in this batch). */
+/* --------------------------------------------------------------------------
+ * scene pair keys -> hit lists (Scene::Scene's key pass, scene.cu:24-55: K1 ppf_kernel + K2
+ * ppf_hash_kernel, fused with the lookup of model.cu:96-97)
+ * ------------------------------------------------------------------------*/
 #define KEY_TILE 4096
+#define COUNT_REFS 8                   /* reference points one counting workgroup handles against its tile */
+
+/* Can the pair (reference point, point at distance vector d) produce a key of the model at all?
+ * Exact: table.reach has a bit for every distance bin that holds a model key, FNV collisions
+ * included; bins beyond the bitset and non-finite distances are kept. */
+__device__ __forceinline__ bool pair_in_reach(const oslamk_vote_args &a, float dx, float dy, float dz)
+{
+    const int k = pc_pair_dist_bin(dx, dy, dz, a.d_dist, a.inv_d_dist);
+    return (unsigned)k >= OSLAMK_REACH_BINS || ((a.table.reach[k >> 5] >> (k & 31)) & 1u);
+}
+
+/* Sizes the hit lists by demand: keep_count[ref] = pairs of the reference point that pass
+ * pair_in_reach (what k_scene_hits keys and probes), an upper bound of its hits -- 16 % above them on
+ * the bench scene.  A workgroup tests its tile of scene points against COUNT_REFS reference points
+ * (their coordinates sit in scalar registers), so a point is loaded once per 8 pairs.
+ * grid (ceil(n_launch / COUNT_REFS), ceil(S / KEY_TILE)). */
+__global__ __launch_bounds__(256) void k_scene_count(oslamk_vote_args a)
+{
+    __shared__ uint32_t s_cnt[COUNT_REFS];
+    const int S = a.scene.n, lane = threadIdx.x & (WAVE - 1);
+    const int g0 = blockIdx.x * COUNT_REFS;
+    uint32_t rr[COUNT_REFS], cnt[COUNT_REFS];
+    float prx[COUNT_REFS], pry[COUNT_REFS], prz[COUNT_REFS];
+#pragma unroll
+    for (int g = 0; g < COUNT_REFS; g++) {
+        const bool v = g0 + g < a.n_launch;
+        rr[g] = v ? a.ref_idx[a.first_ref + g0 + g] : 0xffffffffu;
+        prx[g] = v ? a.scene.px[rr[g]] : 0.0f;
+        pry[g] = v ? a.scene.py[rr[g]] : 0.0f;
+        prz[g] = v ? a.scene.pz[rr[g]] : 0.0f;
+        cnt[g] = 0;
+    }
+    if (threadIdx.x < COUNT_REFS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int c = 0; c < KEY_TILE / 256; c++) {
+        const int i = blockIdx.y * KEY_TILE + c * 256 + threadIdx.x;
+        const bool in = i < S;
+        const float x = in ? a.scene.px[i] : 0.0f, y = in ? a.scene.py[i] : 0.0f, z = in ? a.scene.pz[i] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < COUNT_REFS; g++) {
+            const bool keep = in && (uint32_t)i != rr[g] && pair_in_reach(a, x - prx[g], y - pry[g], z - prz[g]);
+            cnt[g] += (uint32_t)__popcll(__ballot(keep));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < COUNT_REFS; g++)
+            if (cnt[g]) atomicAdd(&s_cnt[g], cnt[g]);
+    }
+    __syncthreads();
+    if (threadIdx.x < COUNT_REFS && g0 + (int)threadIdx.x < a.n_launch && s_cnt[threadIdx.x])
+        atomicAdd(&a.keep_count[g0 + threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+/* The pairs (reference point r, point i) of one tile of KEY_TILE scene points.  Phase 1 (cheap,
+ * every pair): distance bin only; pairs that fail pair_in_reach are dropped, the rest are
+ * compacted into LDS.  Phase 2 (dense lanes): full key, union-table probe; a pair that hits is
+ * appended to r's hit list as {slot of the key in the union table} + {theta_v, i}; one atomic per
+ * wave reserves the places.  The list of r has keep_count[r] places (k_scene_count), which phase 1
+ * cannot exceed.  grid (refs in this batch, ceil(S/KEY_TILE)). */
 __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 {
     __shared__ uint32_t s_list[KEY_TILE];
     __shared__ uint32_t s_n;
-    const int ref_local = blockIdx.y;
+    const int ref_local = blockIdx.x;
     const int ref_ord = a.first_ref + ref_local;
     const int lane = threadIdx.x & (WAVE - 1);
     const int S = a.scene.n;
@@ -566,13 +645,10 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
     __syncthreads();
 
     for (int c = 0; c < KEY_TILE / 256; c++) {
-        const int i = blockIdx.x * KEY_TILE + c * 256 + threadIdx.x;
+        const int i = blockIdx.y * KEY_TILE + c * 256 + threadIdx.x;
         bool keep = false;
-        if (i < S && (uint32_t)i != r) {
-            const int k = pc_pair_dist_bin(a.scene.px[i] - prx, a.scene.py[i] - pry, a.scene.pz[i] - prz,
-                                           a.d_dist, a.inv_d_dist);
-            keep = (unsigned)k >= OSLAMK_REACH_BINS || ((a.table.reach[k >> 5] >> (k & 31)) & 1u);
-        }
+        if (i < S && (uint32_t)i != r)
+            keep = pair_in_reach(a, a.scene.px[i] - prx, a.scene.py[i] - pry, a.scene.pz[i] - prz);
         const unsigned long long km = __ballot(keep);
         if (km) {
             uint32_t base = 0;
@@ -584,13 +660,18 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
     __syncthreads();
 
     const uint32_t n_keep = s_n;
+    if (n_keep == 0) return;
     const float nrx = a.scene.nx[r], nry = a.scene.ny[r], nrz = a.scene.nz[r];
     const float nrn = pc_norm3(nrx, nry, nrz);
     const float *rows = a.tsg + 8 * (size_t)ref_ord;
+    const uint32_t off = a.hit_off[ref_local];
     for (uint32_t j0 = 0; j0 < n_keep; j0 += 256) {
         const uint32_t j = j0 + threadIdx.x;
         bool hit = false;
-        uint4 rec = make_uint4(0, 0, 0, 0);
+        uint32_t slot = 0;
+        oslamk_pay pay;
+        pay.theta_t22 = 0;
+        pay.idx = 0;
         if (j < n_keep) {
             const int i = (int)s_list[j];
             float x, y, z;
@@ -598,7 +679,7 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
                                                 a.inv_d_dist, &x, &y, &z);
             if (key != 0) {                                       /* kernel.cu:491,520 */
                 const uint32_t mask = a.table.ucap - 1;
-                uint32_t slot = slot_of(key, a.table.ushift);
+                slot = slot_of(key, a.table.ushift);
                 for (uint32_t probe = 0; probe <= mask; probe++) {
                     const uint32_t k = a.table.ukeys[slot];
                     if (k == key) { hit = true; break; }
@@ -608,8 +689,8 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
                 if (hit) {
                     const float vy = pc_row_dot(rows, x, y, z);     /* kernel.cu:334-336 */
                     const float vz = pc_row_dot(rows + 4, x, y, z);
-                    rec = make_uint4(key, __builtin_bit_cast(uint32_t, vy), __builtin_bit_cast(uint32_t, vz),
-                                     pc_angle_t22(vy, vz));
+                    pay.theta_t22 = pc_angle_t22(vy, vz);
+                    pay.idx = (uint32_t)i;
                 }
             }
         }
@@ -619,22 +700,25 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
             if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
             base = readlane_u(base, 0);
             if (hit) {
-                const uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-                reinterpret_cast<uint4 *>(a.hits)[(size_t)ref_local * a.hit_stride + base + rank] = rec;
+                const size_t pos = (size_t)off + base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                a.hit_key[pos] = slot;
+                a.hit_pay[pos] = pay;
             }
         }
     }
 }
 
-/* Sorts the hit list of each reference point of the batch by key, so that hits that share a
- * bucket are adjacent (on the bench scene a bucket is hit 3.8 times per reference point on
- * average; streaming it once per run cuts the entry traffic 4.7x), and writes the run list the
- * vote kernel works from: runs[u] = {key, index of the run's first hit}; a run also ends at every
- * multiple of 64 hits, so a run piece is at most one hit per lane; runs[n_runs] = {0, n_hits}.
- * One workgroup per reference point: radix sort of (key, index) in LDS, then the records are
- * gathered into the second list.  A list longer than SORT_MAX is sorted in segments of
- * SORT_MAX hits (a key then has one run per segment it occurs in: its bucket is streamed once
- * per segment instead of once, everything else is unchanged). */
+/* Orders the hit list of each reference point of the batch by key (by the key's slot in the union
+ * table: log2(ucap) bits instead of 32), so that hits that share a bucket are adjacent (on the bench
+ * scene a bucket is hit 3.8 times per reference point on average; streaming it once per run cuts
+ * the entry traffic 4.7x), and writes the run list the vote kernel works from:
+ * runs[u] = {slot | (hits - 1) << 26, index of the run's first hit}; a run also ends at every
+ * multiple of 64 hits, so a run is at most one hit per lane.
+ * One workgroup per reference point: radix sort of (slot, index) in LDS -- rocPRIM's block
+ * primitive (DESIGN.md 4 says why it stays) -- then the payloads are gathered into the second list.
+ * A list longer than SORT_MAX is sorted in segments of SORT_MAX hits (a key then has one run per
+ * segment it occurs in: its bucket is streamed once per segment instead of once, everything else
+ * is unchanged). */
 #define SORT_MAX 16384
 #define SORT_THREADS 1024
 #define SORT_ITEMS (SORT_MAX / SORT_THREADS)
@@ -646,25 +730,26 @@ typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_SMALL_ITEMS, uint
  * same value in every thread). */
 template <int ITEMS, class SORT>
 __device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_sort, uint32_t *s_part, uint32_t *s_last,
-                                                 const uint4 *src, uint4 *dst, uint2 *runs, uint32_t n, uint32_t seg,
-                                                 uint32_t n_runs, int tid, int lane, int wid)
+                                                 const uint32_t *skey, const oslamk_pay *spay, oslamk_pay *dst,
+                                                 oslamk_run *runs, uint32_t n, uint32_t seg, uint32_t n_runs,
+                                                 unsigned bits, int tid, int lane, int wid)
 {
-    /* An LDS radix sort (rocPRIM's block primitive) of (key, index): thread t brings the hits
-     * ITEMS*t .. ITEMS*t+ITEMS-1 and ends up with the same sorted positions in registers.  Places past
-     * the end carry the largest key; the sort is stable and they come last in the input order, so
-     * they also come last among equal keys and the first n sorted positions are the hits. */
+    /* Thread t brings the hits ITEMS*t .. ITEMS*t+ITEMS-1 and ends up with the same sorted positions in
+     * registers.  Places past the end carry all ones; the sort is stable and they come last in the
+     * input order, so they also come last among equal keys and the first n sorted positions are the
+     * hits. */
     const uint32_t i0 = (uint32_t)tid * ITEMS;
     uint32_t key[ITEMS], idx[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const uint32_t i = i0 + k;
-        key[k] = i < n ? src[i].x : 0xffffffffu;
+        key[k] = i < n ? skey[i] : 0xffffffffu;
         idx[k] = i;
     }
-    SORT().sort(key, idx, s_sort);
+    SORT().sort(key, idx, s_sort, 0u, bits);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
-        if (i0 + k < n) dst[i0 + k] = src[idx[k]];
+        if (i0 + k < n) dst[i0 + k] = spay[idx[k]];
     s_last[tid] = key[ITEMS - 1];
     __syncthreads();
     uint32_t heads = 0, cnt = 0;
@@ -694,8 +779,20 @@ __device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_
     }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
-        if ((heads >> k) & 1u) runs[pos++] = make_uint2(key[k], seg + i0 + k);
-    __syncthreads();                    /* the LDS arrays are reused by the next segment */
+        if ((heads >> k) & 1u) {
+            oslamk_run rn;
+            rn.slot_r = key[k];
+            rn.first = seg + i0 + k;
+            runs[pos++] = rn;
+        }
+    __threadfence_block();
+    __syncthreads();                    /* the run heads are written; the LDS arrays are reused by the next segment */
+    /* length of every run = distance to the next head (or to the end of the segment) */
+    for (uint32_t u = (uint32_t)tid; u < total; u += SORT_THREADS) {
+        const uint32_t f0 = runs[n_runs + u].first;
+        const uint32_t f1 = u + 1 < total ? runs[n_runs + u + 1].first : seg + n;
+        runs[n_runs + u].slot_r |= (f1 - f0 - 1u) << OSLAMK_RUN_SHIFT;
+    }
     return total;
 }
 
@@ -709,41 +806,54 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
     __shared__ uint32_t s_last[SORT_THREADS];           /* the last key of every thread's sorted positions */
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const uint32_t n_all = a.hit_count[ref_local];
-    const uint4 *src_all = reinterpret_cast<const uint4 *>(a.hits) + (size_t)ref_local * a.hit_stride;
-    uint4 *dst_all = reinterpret_cast<uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
-    uint2 *runs = reinterpret_cast<uint2 *>(a.runs) + (size_t)ref_local * (a.hit_stride + 1);
+    const size_t off = a.hit_off[ref_local];
+    const unsigned bits = 32u - a.table.ushift;
     uint32_t n_runs = 0;                /* the same value in every thread */
     for (uint32_t seg = 0; seg < n_all; seg += SORT_MAX) {
         const uint32_t n = n_all - seg < SORT_MAX ? n_all - seg : SORT_MAX;
         if (n <= SORT_SMALL_ITEMS * SORT_THREADS)
-            n_runs += sort_segment<SORT_SMALL_ITEMS, hit_block_sort_small>(s_sort.small, s_part, s_last, src_all + seg,
-                                                                           dst_all + seg, runs, n, seg, n_runs, tid, lane, wid);
+            n_runs += sort_segment<SORT_SMALL_ITEMS, hit_block_sort_small>(s_sort.small, s_part, s_last, a.hit_key + off + seg,
+                                                                           a.hit_pay + off + seg, a.hit_sorted + off + seg,
+                                                                           a.runs + off, n, seg, n_runs, bits, tid, lane, wid);
         else
-            n_runs += sort_segment<SORT_ITEMS, hit_block_sort>(s_sort.big, s_part, s_last, src_all + seg, dst_all + seg,
-                                                               runs, n, seg, n_runs, tid, lane, wid);
+            n_runs += sort_segment<SORT_ITEMS, hit_block_sort>(s_sort.big, s_part, s_last, a.hit_key + off + seg,
+                                                               a.hit_pay + off + seg, a.hit_sorted + off + seg, a.runs + off, n,
+                                                               seg, n_runs, bits, tid, lane, wid);
     }
-    if (tid == 0) {
-        runs[n_runs] = make_uint2(0u, n_all);
-        a.run_count[ref_local] = n_runs;
-    }
+    if (tid == 0) a.run_count[ref_local] = n_runs;
 }
 
-/* One workgroup = one (scene reference point, model slice).
+/* --------------------------------------------------------------------------
+ * One workgroup = one (scene reference point, model slice).
  * LDS: acc[1024][32] u32 = 128 KiB (one workgroup per CU, 16 waves).
  * ComputeUniqueVotes (model.cu:95-171) without the vote list: K3/K4
  * (kernel.cu:480-554) accumulate straight into acc, and the sort/histogram/
  * threshold of model.cu:148-170 becomes the scan at the end.
  *
- * Phase 1, all threads: one thread per run of the reference point probes the slice table (one
- * 16-byte slot load per probe); runs whose key is in the slice become items {bucket start, length,
- * first hit, hits}, compacted into this workgroup's scratch in HBM/L2.  A unit of work is one
- * (chunk of 256 entries, hit) pair, i.e. four LDS atomics per lane, and a chunk costs
- * VOTE_STEP_COST more units (after its hits) for its loads and set-up; the running sum of units is
- * kept for every 64th item.
- * Phase 2, no barriers: the units are split into 16 equal ranges, one per wave, so the waves
- * finish together whatever the bucket lengths are.  A wave finds its first item through the
- * coarse sums, keeps a window of 64 items in registers (one per lane, next window prefetched) and
- * walks its range chunk by chunk with the next chunk's loads in flight. */
+ * An item of work is one run of the reference point (hits that share a key) with the key's bucket
+ * in this slice, found by one load of table.uinfo[slice][slot]: there is no probing here and no
+ * list of items.  Its cost is chunks x hits vote iterations (a chunk = 256 entries, an iteration =
+ * one hit voting with the chunk a wave holds in registers: four LDS atomics per lane).
+ *   - Pre-scan, all threads: items above VOTE_GIANT iterations ("giants": the buckets of planar
+ *     surfaces hold 10^4 entries) are queued in LDS.
+ *   - Giants first: cut into units of one chunk x at most 16-32 hits, dealt round-robin to the
+ *     16 waves.
+ *   - Then the rest, dynamically: a wave takes VOTE_BLOCK runs at a time from a counter in LDS
+ *     (descriptors of the block after the current one are in flight) and skips the giants.
+ * No barrier between the two; the waves meet at the end.  The loads of the step after the one
+ * being voted are in flight.
+ * Workgroups b and b + 8 share an XCD (speed only): the slices of one reference point are placed
+ * on one XCD, so its hit and run lists reach one L2 once.
+ * ------------------------------------------------------------------------*/
+#define VOTE_QCAP 1024
+#ifndef VOTE_BLOCK
+#define VOTE_BLOCK 8
+#endif
+#ifndef VOTE_GIANT
+#define VOTE_GIANT 32
+#endif
+#define RUN_SLOT_MASK ((1u << OSLAMK_RUN_SHIFT) - 1u)
+
 template <int MODE>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 {
@@ -751,229 +861,243 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
     __shared__ unsigned long long s_wave64[VOTE_THREADS / WAVE];
-    __shared__ uint32_t s_g, s_lmax, s_base, s_grain;
+    __shared__ uint32_t s_g, s_lmax, s_base, s_qn, s_next;
     __shared__ uint32_t s_tbl[32];
+    __shared__ uint32_t s_q[VOTE_QCAP];
+    __shared__ SlowCtx s_ctx;
     __shared__ unsigned long long s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SlowQueue::CAP : 1];
 
     typedef VoteRegs<MODE> VR;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-    const int n_slices = a.table.n_slices;
-    const int ref_local = (int)(blockIdx.x / n_slices);
+    const uint32_t nsl = (uint32_t)a.table.n_slices;
+    const uint32_t xg = blockIdx.x & 7u, xi = blockIdx.x >> 3;
+    const int ref_local = (int)((xi / nsl) * 8u + xg);
+    const int slice = (int)(xi % nsl);
+    if (ref_local >= a.n_launch) return;             /* the grid is padded to a multiple of 8 reference points */
     const int ref_ord = a.first_ref + ref_local;
-    const int slice = (int)(blockIdx.x % n_slices);
     const uint32_t r = a.ref_idx[ref_ord];
     const uint32_t n_runs = a.run_count[ref_local];
-    const uint4 *hits = reinterpret_cast<const uint4 *>(a.hits_sorted) + (size_t)ref_local * a.hit_stride;
-    const uint2 *runs = reinterpret_cast<const uint2 *>(a.runs) + (size_t)ref_local * (a.hit_stride + 1);
-    uint4 *items = reinterpret_cast<uint4 *>(a.items) + (size_t)blockIdx.x * a.hit_stride;
-    unsigned long long *coarse = a.item_sums + (size_t)blockIdx.x * (a.hit_stride / WAVE + 1);
+    const size_t off = a.hit_off[ref_local];
+    const oslamk_pay *hits = a.hit_sorted + off;
+    const oslamk_run *runs = a.runs + off;
+    const oslamk_uinfo *uinfo = a.table.uinfo + (size_t)slice * a.table.ucap;
+    const uint32_t *e4 = a.ent.e4;
+    const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
+    if (tid == 0) {
+        s_ctx.e4 = e4;
+        s_ctx.uv = a.ent.uv;
+        s_ctx.hits = hits;
+        s_ctx.px = a.scene.px;
+        s_ctx.py = a.scene.py;
+        s_ctx.pz = a.scene.pz;
+        s_ctx.rows = a.tsg + 8 * (size_t)ref_ord;
+    }
+    const SlowCtx *sc = &s_ctx;
 
     for (int c = tid; c < ACC_CELLS / 4; c += VOTE_THREADS) reinterpret_cast<uint4 *>(acc)[c] = make_uint4(0, 0, 0, 0);
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
-    if (tid == 0) s_grain = VOTE_THREADS / WAVE;           /* grains 0..15 are the waves' first ones */
 
-    const oslamk_slot *tab = a.table.slots + (size_t)slice * a.table.cap;
-    const uint32_t mask = a.table.cap - 1, shift = a.table.shift;
-    const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
     unsigned long long my_votes = 0;
     SlowQueue sq;
     sq.q = s_slow + (MODE == 0 ? wid * SlowQueue::CAP : 0);
     sq.n = 0;
 #ifdef VOTE_PROF
     const long long pt0 = clock64();
-    long long pt_busy = 0;
 #endif
 
-    /* ---- phase 1: the items of this (reference point, slice) ---- */
-    unsigned long long total = 0;      /* units so far; the same value in every thread */
-    uint32_t n_items = 0;
-    for (uint32_t r0 = 0; r0 < n_runs; r0 += VOTE_THREADS) {
-        unsigned long long units = 0;
-        uint4 it = make_uint4(0, 0, 0, 0);
-        const uint32_t u = r0 + (uint32_t)tid;
-        if (u < n_runs) {
-            const uint2 rr = runs[u];
-            const uint32_t R = runs[u + 1].y - rr.y;
-            uint32_t slot = slot_of(rr.x, shift);
-            for (uint32_t probe = 0; probe <= mask; probe++) {
-                const uint4 sv = *reinterpret_cast<const uint4 *>(&tab[slot]);
-                if (sv.x == rr.x) {
-                    /* sv.w bit 31: the bucket holds an entry with the marker */
-                    it = make_uint4(sv.y, sv.z | (sv.w & 0x80000000u), rr.y, R);
-                    units = (unsigned long long)((sv.z + 255u) >> 8) * (R + VOTE_STEP_COST);
-                    my_votes += (unsigned long long)sv.z * R;
-                    break;
-                }
-                if (sv.x == 0) break;
-                slot = (slot + 1) & mask;
-            }
-        }
-        const bool live = units != 0;
-        const unsigned long long lm = __ballot(live);
-        unsigned long long incl = units;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const unsigned long long up = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += up;
-        }
-        if (lane == WAVE - 1) {
-            s_wave64[wid] = incl;
-            s_wave[wid] = (uint32_t)__popcll(lm);
+    /* ---- pre-scan: votes of this workgroup, giants into the queue ---- */
+    uint32_t T = VOTE_GIANT;
+    for (bool first = true;; first = false) {
+        if (tid == 0) {
+            s_qn = 0;
+            s_next = 0;
         }
         __syncthreads();
-        unsigned long long before_u = total, all_u = 0;
-        uint32_t before_n = n_items, all_n = 0;
-        for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
-            const unsigned long long vu = s_wave64[w];
-            const uint32_t vn = s_wave[w];
-            if (w < wid) {
-                before_u += vu;
-                before_n += vn;
+        for (uint32_t k0 = 0; k0 < n_runs; k0 += VOTE_THREADS) {
+            const uint32_t k = k0 + (uint32_t)tid;
+            bool giant = false;
+            if (k < n_runs) {
+                const uint32_t sr = runs[k].slot_r;
+                const uint32_t ln = uinfo[sr & RUN_SLOT_MASK].len & 0x7fffffffu, R = (sr >> OSLAMK_RUN_SHIFT) + 1u;
+                if (first) my_votes += (unsigned long long)ln * R;
+                giant = ((ln + 255u) >> 8) * R > T;
             }
-            all_u += vu;
-            all_n += vn;
+            const unsigned long long gm = __ballot(giant);
+            if (gm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(gm));
+                base = readlane_u(base, 0);
+                const uint32_t p = base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
+                if (giant && p < VOTE_QCAP) s_q[p] = k;
+            }
         }
-        if (live) {
-            const uint32_t idx = before_n + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
-            items[idx] = it;
-            if ((idx & (WAVE - 1)) == 0) coarse[idx >> 6] = before_u + incl - units;
-        }
-        total += all_u;
-        n_items += all_n;
-        __syncthreads();            /* s_wave / s_wave64 are rewritten by the next pass */
+        __syncthreads();            /* also: acc zeroed, s_tbl written */
+        if (s_qn <= VOTE_QCAP) break;
+        T *= 2;                     /* more giants than the queue holds: a higher bar, same for every thread */
+        __syncthreads();
     }
-    __threadfence_block();
-    __syncthreads();                /* items and sums visible to every wave; acc zeroed */
+    const uint32_t n_q = uni_u32(s_qn);
+    T = uni_u32(T);
 
-    /* ---- phase 2: this wave's share of the units ---- */
-    total = uni_u64(total);
-    n_items = uni_u32(n_items);
-    /* The units are cut into VOTE_GRAINS equal grains; a wave starts with grain `wid` and takes further
-     * ones from a counter in LDS as it finishes: equal shares by the unit count alone left the waves 21 %
-     * apart at the closing barrier (the cost of a unit varies with the chunk, the cache and the queue). */
-    const unsigned long long grain = (total + VOTE_GRAINS - 1) / VOTE_GRAINS;
-    for (uint32_t gi = uni_u32((uint32_t)wid); total != 0 && (unsigned long long)gi * grain < total;) {
-        const unsigned long long lo = (unsigned long long)gi * grain;
-        const unsigned long long hi = lo + grain < total ? lo + grain : total;
-        {
-            uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(&s_grain, 1u);
-            gi = uni_u32(readlane_u(nxt, 0));       /* the grain after this one */
+    /* ---- the step generator of this wave; all state wave-uniform except the windows ---- */
+    const uint32_t n_blocks = (n_runs + VOTE_BLOCK - 1) / VOTE_BLOCK;
+    uint2 cur_ru = make_uint2(0, 0), cur_inf = make_uint2(0, 0), nxt_ru, nxt_inf;   /* lanes < VOTE_BLOCK: {slot_r, first}, {start, len} */
+    uint32_t cur_b, nxt_b;
+    auto grab = [&]() -> uint32_t {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_next, 1u);
+        return uni_u32(readlane_u(b, 0));
+    };
+    auto fetch = [&](uint32_t b, uint2 &ru, uint2 &inf) {
+        const uint32_t k = b * VOTE_BLOCK + (uint32_t)lane;
+        ru = make_uint2(0, 0);
+        inf = make_uint2(0, 0);
+        if (lane < VOTE_BLOCK && k < n_runs) {
+            const oslamk_run rr = runs[k];
+            const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
+            ru = make_uint2(rr.slot_r, rr.first);
+            inf = make_uint2(ui.start, ui.len);
         }
-#ifdef VOTE_PROF
-        const long long pt_a = clock64();
-#endif
-        /* the block of 64 items that holds unit lo: the last one whose sum is <= lo */
-        const uint32_t n_blocks = (n_items + WAVE - 1) >> 6;
-        uint32_t blk = 0;
-        for (uint32_t base = 0; base < n_blocks; base += WAVE) {
-            const uint32_t bi = base + (uint32_t)lane;
-            const unsigned long long v = bi < n_blocks ? coarse[bi] : ~0ull;
-            const unsigned long long m = __ballot(v <= lo);          /* sums ascend: a prefix of the lanes */
-            if (m) blk = base + (uint32_t)__popcll(m) - 1u;
-            if (m != ~0ull) break;
-        }
-        blk = uni_u32(blk);
-        uint32_t wbase = blk << 6;                                   /* first item of the window */
-        auto load_window = [&](uint32_t first) -> uint4 {
-            const uint32_t k = first + (uint32_t)lane;
-            return k < n_items ? items[k] : make_uint4(0, 0, 0, 0);
-        };
-        uint4 win = load_window(wbase), win_next = load_window(wbase + WAVE);
-        /* the item inside the window: exclusive sums of the window's units */
-        uint32_t kl;
-        uint32_t o;
-        {
-            const unsigned long long wu64 = win.w ? (unsigned long long)(((win.y & 0x7fffffffu) + 255u) >> 8) * (win.w + VOTE_STEP_COST) : 0ull;
-            unsigned long long incl = wu64;
-            for (int s2 = 1; s2 < WAVE; s2 <<= 1) {
-                const unsigned long long up = __shfl_up(incl, s2, WAVE);
-                if (lane >= s2) incl += up;
-            }
-            const unsigned long long pref = coarse[blk] + incl - wu64;
-            const unsigned long long m = __ballot(wu64 != 0 && pref <= lo);
-            kl = (uint32_t)__popcll(m) - 1u;                         /* m != 0: the block's first item qualifies */
-            const unsigned long long d = lo - pref;
-            o = readlane_u((uint32_t)d, (int)kl);
-        }
-        /* generator state, wave-uniform.  The budget is handed out in 32-bit portions so that the
-         * per-step arithmetic stays 32-bit (a portion only ends early in absurdly large cases). */
-        unsigned long long budget = hi - lo;
-        uint32_t remaining = 0;
-        uint32_t g_st = 0, g_ln = 0, g_h0 = 0, g_R = 1, g_C = 0, g_c, g_i0;
-        bool g_bf = false;
-        auto open_item = [&]() {
-            g_st = readlane_u(win.x, (int)kl);
-            const uint32_t lf = readlane_u(win.y, (int)kl);
-            g_ln = lf & 0x7fffffffu;
-            g_bf = (lf >> 31) != 0;
-            g_h0 = readlane_u(win.z, (int)kl);
-            g_R = readlane_u(win.w, (int)kl) + VOTE_STEP_COST;   /* hits + the units that stand for the step itself */
-            g_C = (g_ln + 255u) >> 8;
-        };
-        open_item();
-        g_c = o / g_R;
-        g_i0 = o - g_c * g_R;
-        auto next_step = [&]() -> VoteStep {
-            VoteStep d;
-            d.valid = remaining != 0;
-            if (d.valid) {
-                if (g_c == g_C) {                  /* the previous step finished its item */
-                    kl++;
-                    if (kl == WAVE) {              /* next window; the one after it goes in flight */
-                        win = win_next;
-                        wbase += WAVE;
-                        kl = 0;
-                        win_next = load_window(wbase + WAVE);
+    };
+    /* the items of the current block this wave votes: present in the slice and not a giant */
+    auto examine = [&]() -> unsigned long long {
+        const uint32_t ln = cur_inf.y & 0x7fffffffu, R = (cur_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+        return __ballot(ln != 0u && ((ln + 255u) >> 8) * R <= T);
+    };
+    cur_b = grab();
+    fetch(cur_b, cur_ru, cur_inf);
+    nxt_b = grab();
+    fetch(nxt_b, nxt_ru, nxt_inf);
+
+    /* giants: window of 64 queued items, one per lane */
+    uint32_t g_tw = 0, g_base = 0, g_tot = 0, g_u = uni_u32((uint32_t)wid);
+    uint2 gw_ru = make_uint2(0, 0), gw_inf = make_uint2(0, 0);
+    uint32_t gw_incl = 0, gw_nu = 0;
+    bool giants = n_q != 0;
+    /* small items */
+    unsigned long long s_m = 0;
+    bool s_open = false;
+    uint32_t it_st = 0, it_ln = 0, it_h0 = 0, it_R = 1, it_C = 0, it_c = 0;
+    bool it_bf = false;
+
+    auto next_step = [&]() -> VoteStep {
+        VoteStep d;
+        d.valid = false;
+        for (;;) {
+            if (giants) {
+                if (g_u < g_base + g_tot) {
+                    const unsigned long long m = __ballot(g_base + gw_incl > g_u);   /* a suffix of the lanes */
+                    const int tl = __ffsll((long long)m) - 1;
+                    const uint32_t excl = readlane_u(gw_incl - gw_nu, tl);
+                    const uint32_t sr = readlane_u(gw_ru.x, tl), lf = readlane_u(gw_inf.y, tl);
+                    const uint32_t ln = lf & 0x7fffffffu, R = (sr >> OSLAMK_RUN_SHIFT) + 1u;
+                    const uint32_t lg = R > 32u ? 2u : R > 16u ? 1u : 0u;          /* the hits of a chunk in 1, 2 or 4 units */
+                    const uint32_t local = g_u - g_base - excl, c = local >> lg, hs = local & ((1u << lg) - 1u);
+                    const uint32_t per = (R + (1u << lg) - 1u) >> lg;
+                    d.e0 = readlane_u(gw_inf.x, tl) + (c << 8);
+                    d.left = ln - (c << 8);
+                    d.h0 = readlane_u(gw_ru.y, tl);
+                    d.R = R;
+                    d.i0 = (int)(hs * per);
+                    d.i1 = (int)(hs * per + per < R ? hs * per + per : R);
+                    d.bforced = (lf >> 31) != 0;
+                    d.valid = true;
+                    g_u += VOTE_THREADS / WAVE;
+                    return d;
+                }
+                g_base += g_tot;
+                g_tot = 0;
+                if (g_tw >= n_q) {
+                    giants = false;
+                    continue;
+                }
+                {
+                    const uint32_t t = g_tw + (uint32_t)lane;
+                    gw_ru = make_uint2(0, 0);
+                    gw_inf = make_uint2(0, 0);
+                    gw_nu = 0;
+                    if (t < n_q) {
+                        const oslamk_run rr = runs[s_q[t]];
+                        const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
+                        const uint32_t R = (rr.slot_r >> OSLAMK_RUN_SHIFT) + 1u;
+                        gw_ru = make_uint2(rr.slot_r, rr.first);
+                        gw_inf = make_uint2(ui.start, ui.len);
+                        gw_nu = (((ui.len & 0x7fffffffu) + 255u) >> 8) << (R > 32u ? 2u : R > 16u ? 1u : 0u);
                     }
-                    open_item();
-                    g_c = 0;
+                    uint32_t incl = gw_nu;
+                    for (int o = 1; o < WAVE; o <<= 1) {
+                        const uint32_t up = __shfl_up(incl, o, WAVE);
+                        if (lane >= o) incl += up;
+                    }
+                    gw_incl = incl;
+                    g_tot = readlane_u(incl, WAVE - 1);
+                    g_tw += WAVE;
                 }
-                const uint32_t off = g_c << 8;
-                d.chunk = a.ent.e4 + g_st + off;
-                d.hit0 = hits + g_h0;
-                d.left = g_ln - off;
-                d.entry0 = g_st + off;
-                d.hbase = g_h0;
-                d.R = g_R - VOTE_STEP_COST;
-                d.bforced = g_bf;
-                d.i0 = (int)g_i0;
-                uint32_t nh = g_R - g_i0;
-                nh = nh < remaining ? nh : remaining;
-                d.i1 = (int)(g_i0 + nh);
-                remaining -= nh;
-                g_i0 = 0;
-                g_c++;
+                continue;
             }
-            return d;
-        };
-        while (budget) {
-            remaining = budget > 0x40000000ull ? 0x40000000u : (uint32_t)budget;
-            budget -= remaining;
-            /* the loads of the next VOTE_PIPE steps are in flight while a step is voted: the kernel is
-             * bound by the latency of the entry stream (HBM / Infinity Cache), not by issue */
-            VR c[VOTE_PIPE + 1];
-            VoteStep d[VOTE_PIPE + 1];
-#pragma unroll
-            for (int k = 0; k < VOTE_PIPE; k++) {
-                d[k] = next_step();
-                if (d[k].valid) c[k].load(d[k], lane);
+            if (it_c < it_C) {
+                const uint32_t o = it_c << 8;
+                d.e0 = it_st + o;
+                d.left = it_ln - o;
+                d.h0 = it_h0;
+                d.R = it_R;
+                d.i0 = 0;
+                d.i1 = (int)it_R;
+                d.bforced = it_bf;
+                d.valid = true;
+                it_c++;
+                return d;
             }
-            while (d[0].valid) {
-                d[VOTE_PIPE] = next_step();
-                if (d[VOTE_PIPE].valid) c[VOTE_PIPE].load(d[VOTE_PIPE], lane);
-                c[0].vote(a, hits, acc, s_tbl, sq, d[0], lane);
-#pragma unroll
-                for (int k = 0; k < VOTE_PIPE; k++) {
-                    c[k] = c[k + 1];
-                    d[k] = d[k + 1];
-                }
+            if (!s_open) {                        /* first look at the first block */
+                s_open = true;
+                s_m = cur_b < n_blocks ? examine() : 0ull;
+            }
+            while (s_m == 0ull) {
+                if (cur_b >= n_blocks) return d;  /* this wave is done (the counter only grows) */
+                cur_ru = nxt_ru;
+                cur_inf = nxt_inf;
+                cur_b = nxt_b;
+                if (cur_b >= n_blocks) return d;
+                nxt_b = grab();
+                fetch(nxt_b, nxt_ru, nxt_inf);
+                s_m = examine();
+            }
+            {
+                const int j = __ffsll((long long)s_m) - 1;
+                s_m &= s_m - 1ull;
+                const uint32_t sr = readlane_u(cur_ru.x, j), lf = readlane_u(cur_inf.y, j);
+                it_st = readlane_u(cur_inf.x, j);
+                it_ln = lf & 0x7fffffffu;
+                it_bf = (lf >> 31) != 0;
+                it_h0 = readlane_u(cur_ru.y, j);
+                it_R = (sr >> OSLAMK_RUN_SHIFT) + 1u;
+                it_C = (it_ln + 255u) >> 8;
+                it_c = 0;
             }
         }
-#ifdef VOTE_PROF
-        pt_busy += clock64() - pt_a;
+    };
+
+    /* ---- voting: the loads of the next step are in flight while a step is voted ---- */
+    {
+        VR rA, rB;
+        VoteStep dA = next_step(), dB;
+        if (dA.valid) rA.load(e4, hits, dA, lane);
+        while (dA.valid) {
+            dB = next_step();
+            if (dB.valid) rB.load(e4, hits, dB, lane);
+            rA.vote(sc, acc, s_tbl, sq, dA, lane);
+#ifdef VOTE_AB
+            if (!dB.valid) break;
+            dA = next_step();
+            if (dA.valid) rA.load(e4, hits, dA, lane);
+            rB.vote(sc, acc, s_tbl, sq, dB, lane);
+#else
+            rA = rB;
+            dA = dB;
 #endif
+        }
     }
-    if (MODE == 0) sq.flush(a, hits, acc, s_tbl, lane);
+    if (MODE == 0) sq.flush(sc, acc, s_tbl, lane);
 #ifdef VOTE_PROF
     const long long pt1 = clock64();
 #endif
@@ -984,7 +1108,6 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     if (lane == 0) {
         atomicAdd(&a.counters->prof[0], (unsigned long long)(pt1 - pt0));
         atomicAdd(&a.counters->prof[1], (unsigned long long)(pt2 - pt0));
-        atomicAdd(&a.counters->prof[3], (unsigned long long)pt_busy);
     }
 #endif
 
@@ -1007,7 +1130,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     if (tid == 0) {
         uint32_t m = 0, n = 0;
         /* hits are counted once per reference point */
-        unsigned long long h = slice == 0 ? (unsigned long long)runs[n_runs].y : 0ull, v = 0;
+        unsigned long long h = slice == 0 ? (unsigned long long)a.hit_count[ref_local] : 0ull, v = 0;
         for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
             m = s_wave[w] > m ? s_wave[w] : m;
             n += s_wave2[w];
@@ -1230,10 +1353,25 @@ int oslamk_reach_build(oslamk_table t, float d_dist, void *stream)
     return (int)hipGetLastError();
 }
 
+int oslamk_uinfo_build(oslamk_table t, void *stream)
+{
+    const size_t total = (size_t)t.n_slices * t.cap;
+    hipLaunchKernelGGL(k_uinfo_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t);
+    return (int)hipGetLastError();
+}
+
+int oslamk_scene_count(const oslamk_vote_args *a, void *stream)
+{
+    if (a->n_launch <= 0) return 0;
+    dim3 grid((unsigned)((a->n_launch + COUNT_REFS - 1) / COUNT_REFS), (unsigned)((a->scene.n + KEY_TILE - 1) / KEY_TILE));
+    hipLaunchKernelGGL(k_scene_count, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}
+
 int oslamk_scene_hits(const oslamk_vote_args *a, void *stream)
 {
     if (a->n_launch <= 0) return 0;
-    dim3 grid((unsigned)((a->scene.n + KEY_TILE - 1) / KEY_TILE), (unsigned)a->n_launch);
+    dim3 grid((unsigned)a->n_launch, (unsigned)((a->scene.n + KEY_TILE - 1) / KEY_TILE));
     hipLaunchKernelGGL(k_scene_hits, grid, dim3(256), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }
@@ -1248,7 +1386,8 @@ int oslamk_sort_hits(const oslamk_vote_args *a, void *stream)
 int oslamk_vote(const oslamk_vote_args *a, void *stream)
 {
     if (a->n_launch <= 0) return 0;
-    dim3 grid((unsigned)((size_t)a->n_launch * a->table.n_slices));
+    /* padded to groups of 8 reference points: see the workgroup -> (reference point, slice) map in k_vote */
+    dim3 grid((unsigned)(((size_t)a->n_launch + 7) / 8 * 8 * a->table.n_slices));
     if (a->mode == 0)
         hipLaunchKernelGGL(k_vote<0>, grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
     else

@@ -139,6 +139,42 @@ static int pool_reserve(pose_pool *p, size_t bytes, size_t tmp_bytes)
     return 0;
 }
 
+/* the records with count > min_votecount, compacted in their order into d_out (device, capacity n_in) */
+extern "C" int oslamk_select_cells(const oslamk_cell *d_in, uint32_t n_in, float min_votecount, oslamk_cell *d_out,
+                                   uint32_t *n_out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = 0, dev = 0;
+    size_t tmp = 0;
+    uint32_t n = 0;
+    pose_pool *pool;
+    *n_out = 0;
+    if (n_in == 0) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    pool = &g_pool[dev];
+    PCHK(rocprim::select(nullptr, tmp, d_in, (oslamk_cell *)nullptr, (uint32_t *)nullptr, (size_t)n_in, cell_above{min_votecount}, stream));
+    rc = pool_reserve(pool, 256, tmp ? tmp : 16);
+    if (rc != 0) goto done;
+    PCHK(rocprim::select(pool->tmp, tmp, d_in, d_out, (uint32_t *)pool->d, (size_t)n_in, cell_above{min_votecount}, stream));
+    PCHK(hipMemcpyAsync(&n, pool->d, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    PCHK(hipStreamSynchronize(stream));
+    *n_out = n;
+done:
+    return rc;
+}
+
+/* frees the tail's work space on the current device */
+extern "C" void oslamk_pose_release(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    if (g_pool[dev].d) (void)hipFree(g_pool[dev].d);
+    if (g_pool[dev].tmp) (void)hipFree(g_pool[dev].tmp);
+    g_pool[dev].d = NULL;
+    g_pool[dev].tmp = NULL;
+    g_pool[dev].cap = g_pool[dev].tmp_cap = 0;
+}
+
 /* d_cells_in[n_in]: emitted peak records (device).  Outputs (device, caller-owned, capacity n_in):
  * d_cells_out = the kept cells in (count desc, code asc) order, d_poses = 16 floats per kept cell.
  * Host outputs: *n_out kept cells, *best_out index of the winning pose, T_best its matrix with the

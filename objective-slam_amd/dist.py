@@ -2,25 +2,74 @@
 points dealt round-robin to ranks (include/oslam.h: params.shard_rank/shard_world),
 no collective on the vote path.  After the local vote kernels every rank holds its
 peak records (count > threshold * local maximum) and its local maximum; this module
-does the only exchange: an all-reduce(MAX) of the maxima and an all-gather of
-fixed-size record blocks (16 B per record; 4 KiB to a few hundred KiB per rank).  Backend "nccl" is RCCL over
-xGMI on the GPU node; "gloo" runs the same code on CPUs (tests/test_distributed.py).
+does the only exchange: an all-reduce(MAX) of the maxima and an all-gather of the records above
+the global threshold (16 B per record; 4 KiB to a few hundred KiB per rank).  On GPUs the exchange
+lives behind the C-ABI (oslam_align_multi: RCCL over xGMI, device buffers end to end; make_comm
+below only carries the communicator id to the ranks); the host-buffer form of the same steps over
+torch.distributed ("gloo") is what tests/test_distributed.py runs on CPUs.
 The reference has no multi-GPU code (src/cuda/ppf.cu:45 picks one device)."""
 import numpy as np
 
 from . import ppf
 
-LOCAL_CAP = 1 << 18   # records a rank may hold before the global threshold is known
 MIN_BLOCK = 256       # smallest all-gather block, in records (4 KiB)
 
 
-def gather_peaks(cells, local_max, device, vote_count_threshold=0.4):
-    """cells: this rank's peak records (ppf.CELL_DTYPE, count > threshold * local maximum).
-    Returns (union over ranks of the records with count > threshold * GLOBAL maximum, global maximum).
+def make_comm(device_index):
+    """RCCL communicator for oslam_align_multi: rank 0's id travels through torch.distributed (any
+    backend), then every rank joins with ncclCommInitRank inside the library."""
+    import torch.distributed as dist
 
-    Three collectives, all tiny: all-reduce(MAX) of the vote maximum (the reference's threshold is
-    global, model.cu:164-170); all-reduce(MAX) of the number of surviving records, which sizes the
-    blocks; all-gather of one fixed-size block of 16-byte records per rank."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [ppf.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return ppf.Comm(box[0], rank, world, device_index)
+
+
+def align_multi(model, scene, comm):
+    """The whole multi-GPU registration of one model in one C call per rank (device buffers end to end)."""
+    return model.align_multi(scene, comm, allow_no_votes=True)
+
+
+def align_sharded_host(model, scene, device, vote_count_threshold=0.4):
+    """The same exchange through host buffers and torch.distributed collectives (gloo on CPUs, tests):
+    votes of this rank, all-reduce(MAX) of the maxima, then the records above the GLOBAL threshold --
+    all of them, whatever their number -- all-gathered in fixed-size blocks.  Returns (union, global max)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    _, lmax = model.align_local(scene)                                    # records stay with the model
+    meta = torch.tensor([int(lmax)], dtype=torch.int64, device=device)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX)
+    gmax = int(meta.item())
+    mine = model.local_peaks(gmax)
+    return gather_records(mine, device, world), gmax
+
+
+def gather_records(mine, device, world):
+    """All-gather of variable-length record lists in fixed-size blocks (16 B per record)."""
+    import torch
+    import torch.distributed as dist
+
+    meta = torch.tensor([len(mine)], dtype=torch.int64, device=device)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX)
+    block = MIN_BLOCK
+    while block < int(meta.item()):
+        block *= 2
+    host = np.zeros(block * 2, np.int64)
+    if len(mine):
+        host[: 2 * len(mine)] = np.ascontiguousarray(mine).view(np.int64).reshape(-1)
+    send = torch.from_numpy(host).to(device)
+    recv = torch.zeros(world * block * 2, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    allrec = recv.cpu().numpy().view(ppf.CELL_DTYPE)
+    return allrec[allrec["count"] > 0].copy()
+
+
+def gather_peaks(cells, local_max, device, vote_count_threshold=0.4):
+    """cells: this rank's peak records (ppf.CELL_DTYPE, count > threshold * local maximum), complete.
+    Returns (union over ranks of the records with count > threshold * GLOBAL maximum, global maximum)."""
     import torch
     import torch.distributed as dist
 
@@ -30,19 +79,7 @@ def gather_peaks(cells, local_max, device, vote_count_threshold=0.4):
     gmax = int(meta.item())
     bound = np.float32(vote_count_threshold) * np.float32(gmax)          # float compare, as model.cu:164-167
     mine = np.ascontiguousarray(cells[cells["count"].astype(np.float32) > bound])
-    meta = torch.tensor([len(mine)], dtype=torch.int64, device=device)
-    dist.all_reduce(meta, op=dist.ReduceOp.MAX)
-    block = MIN_BLOCK
-    while block < int(meta.item()):
-        block *= 2
-    host = np.zeros(block * 2, np.int64)
-    if len(mine):
-        host[: 2 * len(mine)] = mine.view(np.int64).reshape(-1)
-    send = torch.from_numpy(host).to(device)
-    recv = torch.zeros(world * block * 2, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(recv, send)                               # per-GPU top pose votes
-    allrec = recv.cpu().numpy().view(ppf.CELL_DTYPE)
-    return allrec[allrec["count"] > 0].copy(), gmax
+    return gather_records(mine, device, world), gmax
 
 
 def finish_on_host(cells, global_max, m_pts, m_nrm, s_pts, s_nrm, d_dist, vote_count_threshold=0.4,

@@ -21,6 +21,7 @@ _LIB = None
 
 OSLAM_OK, OSLAM_E_INVALID, OSLAM_E_DEVICE, OSLAM_E_NOMEM, OSLAM_E_NO_VOTES, OSLAM_E_LIMIT = range(6)
 VOTE_EXACT, VOTE_FAST = 0, 1
+COMM_ID_BYTES = 128
 
 
 class OslamError(RuntimeError):
@@ -41,10 +42,11 @@ class Stats(C.Structure):
                 ("num_unique_votes", C.c_uint64), ("num_model_keys", C.c_uint64), ("num_top", C.c_uint64),
                 ("max_count", C.c_uint32), ("num_emitted", C.c_uint32), ("ms_vote", C.c_float),
                 ("ms_total", C.c_float), ("vote_launches", C.c_uint32), ("ms_vote_kernel", C.c_float),
-                ("ms_key_kernel", C.c_float), ("reserved", C.c_uint32 * 3)]
+                ("ms_key_kernel", C.c_float), ("reserved0", C.c_uint32), ("num_pairs_probed", C.c_uint64),
+                ("scratch_bytes", C.c_uint64)]
 
     def asdict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved0"}
 
 
 CELL_DTYPE = np.dtype([("code", "<u8"), ("count", "<u4"), ("pad", "<u4")])
@@ -78,6 +80,12 @@ _SIGNATURES = {
     "oslam_pose_stage": (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _f, _i, _i, _i, _vp, _vp, _vp]),
     "oslam_align_local": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     "oslam_align_finish": (_i, [_vp, _vp, _vp, _sz, C.c_uint32, _vp, C.POINTER(Stats)]),
+    "oslam_local_peaks": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "oslam_comm_unique_id": (_i, [_vp]),
+    "oslam_comm_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    "oslam_comm_destroy": (None, [_vp]),
+    "oslam_align_multi": (_i, [_vp, _vp, _vp, _vp, C.POINTER(Stats)]),
+    "oslam_release_scratch": (_i, [_i]),
     "oslam_scene_keys": (_i, [_vp, _sz, _vp]),
     "oslam_model_keys": (_i, [_vp, _sz, _vp]),
     "oslam_model_bucket": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
@@ -274,14 +282,42 @@ class Model:
         self.stats = st.asdict()
         return self.best_T
 
-    def align_local(self, scene, cap=4096):
-        cells = np.zeros(cap, CELL_DTYPE)
+    def align_local(self, scene, cap=None):
+        """This rank's votes.  cap=None: returns (number of peaks above the LOCAL threshold, local maximum) and
+        leaves the records with the model for local_peaks(); with a cap: (records, local maximum), and
+        OSLAM_E_LIMIT is raised when they do not fit (nothing is cut silently)."""
         n = C.c_size_t(0)
         lmax = C.c_uint32(0)
         st = Stats()
+        if cap is None:
+            _check(lib().oslam_align_local(self._h, scene._h, None, 0, C.byref(n), C.byref(lmax), C.byref(st)))
+            self.stats = st.asdict()
+            return int(n.value), int(lmax.value)
+        cells = np.zeros(cap, CELL_DTYPE)
         _check(lib().oslam_align_local(self._h, scene._h, _p(cells), cap, C.byref(n), C.byref(lmax), C.byref(st)))
         self.stats = st.asdict()
         return cells[: n.value].copy(), int(lmax.value)
+
+    def local_peaks(self, global_max):
+        """Records of the last align_local above threshold * global_max (oslam_local_peaks)."""
+        n = C.c_size_t(0)
+        rc = lib().oslam_local_peaks(self._h, int(global_max), None, 0, C.byref(n))
+        if rc not in (OSLAM_OK, OSLAM_E_LIMIT):
+            _check(rc)
+        cells = np.zeros(max(n.value, 1), CELL_DTYPE)
+        _check(lib().oslam_local_peaks(self._h, int(global_max), _p(cells), len(cells), C.byref(n)))
+        return cells[: n.value].copy()
+
+    def align_multi(self, scene, comm, allow_no_votes=False):
+        """One call per rank: votes of this rank's shard, RCCL exchange, pose tail on the union (oslam_align_multi)."""
+        T = np.zeros(16, np.float32)
+        st = Stats()
+        rc = lib().oslam_align_multi(self._h, scene._h, comm._h, _p(T), C.byref(st))
+        if not (allow_no_votes and rc == OSLAM_E_NO_VOTES):
+            _check(rc)
+        self.best_T = T.reshape(4, 4)
+        self.stats = st.asdict()
+        return self.best_T
 
     def align_finish(self, scene, cells, global_max, allow_no_votes=False):
         cells = np.ascontiguousarray(cells, CELL_DTYPE)
@@ -343,6 +379,38 @@ class Model:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """RCCL communicator of the multi-GPU path (oslam_comm): rank 0 makes the id, everybody gets its bytes
+    (here: through torch.distributed, any backend) and creates its end."""
+
+    def __init__(self, id_bytes, rank, world, dev):
+        self._h = C.c_void_p(0)
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        _check(lib().oslam_comm_create(buf, int(rank), int(world), int(dev), C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * COMM_ID_BYTES)()
+        _check(lib().oslam_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if self._h:
+            lib().oslam_comm_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def release_scratch(dev=0):
+    _check(lib().oslam_release_scratch(int(dev)))
 
 
 def ppf_registration(scene_clouds, model_clouds, model_d_dists, ref_point_downsample_factor=1,
