@@ -426,7 +426,7 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     oslam_T_g_rows(m->c.h_xyz, m->c.h_nrm, NULL, n, h_tmg);
     HIPCHK(hipMalloc((void **)&d_tmg, sizeof(float) * 8 * n));
     HIPCHK(hipMemcpy(d_tmg, h_tmg, sizeof(float) * 8 * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * n_pairs));
+    HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * (n_pairs + 256)));   /* + a chunk: the vote kernel loads whole chunks */
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
     if (m->params.vote_mode != OSLAM_VOTE_FAST)
         HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
@@ -648,7 +648,7 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     HIPCHK(hipMalloc((void **)&m->table.slots, sizeof(oslamk_slot) * n_slots));
     HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap));
     HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
-    HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * n_pairs));
+    HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * (n_pairs + 256)));   /* + a chunk: the vote kernel loads whole chunks */
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
     if (hd.has_uv) HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
     HIPCHK(hipMemcpy(m->table.slots, h_slots, sizeof(oslamk_slot) * n_slots, hipMemcpyHostToDevice));
@@ -950,7 +950,7 @@ done:
 
 static int pool_reserve_slots(scratch_pool *p, size_t slots)
 {
-    size_t want = (slots ? slots : 1) * SLOT_BYTES;
+    size_t want = (slots ? slots : 1) * SLOT_BYTES + 1024;      /* + a wave of hits: the vote kernel loads 64 at a time */
     if (p->bytes >= want) return OSLAM_OK;
     if (p->buf) { (void)hipFree(p->buf); p->buf = NULL; p->bytes = 0; }
     want += want / 8;                 /* head room: the next scene is rarely the same size */
@@ -958,7 +958,7 @@ static int pool_reserve_slots(scratch_pool *p, size_t slots)
     if (hipMalloc((void **)&p->buf, want) != hipSuccess) {
         (void)hipGetLastError();
         p->buf = NULL;
-        want = (slots ? slots : 1) * SLOT_BYTES;
+        want = (slots ? slots : 1) * SLOT_BYTES + 1024;
         if (hipMalloc((void **)&p->buf, want) != hipSuccess) {
             (void)hipGetLastError();
             p->buf = NULL;

@@ -121,7 +121,8 @@ typedef struct oslamk_pay {
 /* A run of hits of one reference point that share a key (at most 64 of them). */
 typedef struct oslamk_run {
     uint32_t slot_r;           /* union-table slot of the key | (hits - 1) << OSLAMK_RUN_SHIFT */
-    uint32_t first;            /* first hit of the run in the reference point's sorted hit list */
+    uint32_t first;            /* first hit of the run in the reference point's sorted hit list; bit 31: a hit of the run carries
+                                * the "always re-evaluate" marker */
 } oslamk_run;
 #define OSLAMK_RUN_SHIFT 26    /* union tables have at most 2^26 slots */
 

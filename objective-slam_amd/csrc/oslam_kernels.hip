@@ -399,32 +399,17 @@ struct SlowCtx {
     const float *rows;
 };
 
-/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index, hit index};
- * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
- * a time by flush(). */
-struct SlowQueue {
-    static constexpr uint32_t CAP = 96;
-    unsigned long long *q;              /* entry index | hit index << 32 */
-    uint32_t n;                        /* wave-uniform */
-    __device__ __forceinline__ void push(unsigned long long mask, int lane, uint32_t entry, uint32_t hit)
-    {
-        if ((mask >> lane) & 1ull) {
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            q[n + rank] = (unsigned long long)entry | ((unsigned long long)hit << 32);
-        }
-        n += (uint32_t)__popcll(mask);
-    }
-    __device__ __forceinline__ void flush(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, int lane);
-};
-
-/* LDS pointers of the out-of-line flush; its context lives in LDS too (a kernel's stack would be scratch memory) */
+/* LDS pointers of the out-of-line paths; their context lives in LDS too (a kernel's stack would be scratch memory) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) const SlowCtx lds_ctx;
 
-/* Out of line on purpose: inlined, its loads make the compiler wait for the prefetched chunk at the
- * top of the vote loop (it cannot tell the two apart at the loop head); a call site settles that. */
-__device__ __noinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_cu64 *q, uint32_t n, int lane)
+/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index, hit index};
+ * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
+ * a time by slow_queue_flush().  q: the wave's SLOW_CAP places; n: how many are taken (wave-uniform). */
+#define SLOW_CAP 96
+
+__device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n, int lane)
 {
     const uint32_t *t = (const uint32_t *)tbl;
     for (uint32_t base = 0; base < n; base += WAVE) {
@@ -443,10 +428,17 @@ __device__ __noinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_u32
     }
 }
 
-__device__ __forceinline__ void SlowQueue::flush(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, int lane)
+/* appends the votes of `mask`'s lanes (entry, hit) to the wave's queue, emptying it first when they would not fit */
+__device__ __forceinline__ uint32_t slow_push(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n,
+                                              unsigned long long mask, uint32_t entry, uint32_t hit, int lane)
 {
-    if (n) slow_queue_flush((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)tbl, (lds_cu64 *)q, n, lane);
-    n = 0;
+    if (n > SLOW_CAP - WAVE) {
+        slow_queue_flush(sc, acc, tbl, q, n, lane);
+        n = 0;
+    }
+    if ((mask >> lane) & 1ull)
+        q[n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned long long)entry | ((unsigned long long)hit << 32);
+    return n + (uint32_t)__popcll(mask);
 }
 
 /* One step of a wave (all fields wave-uniform): one chunk of a bucket voted by the hits
@@ -456,63 +448,71 @@ struct VoteStep {
     uint32_t left;                     /* entries from the chunk start to the bucket end (>= 1) */
     uint32_t h0;                       /* index of the run's first hit in the reference point's sorted list */
     uint32_t R;                        /* hits of the run */
-    int i0, i1;                        /* the hits of the run that vote in this step */
-    bool bforced, valid;               /* bforced: the bucket holds an entry with the marker */
+    uint32_t i0, i1;                   /* the hits of the run that vote in this step */
+    bool valid;
 };
 
+/* An item whose every vote is re-evaluated with the reference's float sequence -- its bucket holds an
+ * entry with the marker, or one of its hits carries it (degenerate geometry: a second point on the
+ * reference point's normal, a non-finite coordinate): every (entry, hit) pair goes through the queue.
+ * Rare and slow on purpose; called after the vote loop, never from inside it. */
+__device__ __noinline__ uint32_t forced_item(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n, uint32_t st,
+                                             uint32_t ln, uint32_t h0, uint32_t R, int lane)
+{
+    for (uint32_t e = 0; e < ln; e += WAVE) {
+        const unsigned long long nm = __ballot(e + (uint32_t)lane < ln);
+        for (uint32_t i = 0; i < R; i++) n = slow_push(sc, acc, tbl, q, n, nm, st + e + (uint32_t)lane, h0 + i, lane);
+    }
+    return n;
+}
+
+/* The registers of a step in flight and its votes: lane l holds entries 4l .. 4l+3 of the chunk (one
+ * 16-byte load) and theta_v of hit `lane` of the run.  One code path for full and partial chunks: the
+ * atomics are issued with EXEC narrowed to the lanes that hold entries, so idle lanes cost no LDS cycles
+ * and cause no bank conflicts; the one lane that holds fewer than four entries sends the rest to its
+ * trash word.  Written in asm because the compiler has no way to say this; the workgroup waits for these
+ * atomics (lgkmcnt) before it reads the accumulator.  Per hit (256 votes): readlane + 19 vector
+ * instructions (exact mode) + compare/branch + 4 LDS atomics + loop control.  Items that carry a marker
+ * never come here (forced_item). */
 template <int MODE>
 struct VoteRegs {
-    uint4 v;                           /* 4 entries of the chunk: lane l holds entries 4l .. 4l+3 */
-    uint32_t th;                       /* theta_v of hit `lane` of the run */
+    uint4 v;
+    uint32_t th;
+    /* Unconditional on purpose: every lane loads, whatever the chunk and the run hold, so that the loads of
+     * a group are straight-line code and the compiler can wait for each member's registers alone
+     * (vmcnt(N)) instead of draining everything. */
     __device__ __forceinline__ void load(const uint32_t *e4, const oslamk_pay *hits, const VoteStep &d, int lane)
     {
-        if (4u * (uint32_t)lane < d.left) v = reinterpret_cast<const uint4 *>(e4 + d.e0)[lane];
-        if ((uint32_t)lane < d.R) th = hits[d.h0 + (uint32_t)lane].theta_t22;
+        /* lanes past the end of the bucket / the run re-read its first bytes (no extra traffic) */
+        v = reinterpret_cast<const uint4 *>(e4 + d.e0)[4u * (uint32_t)lane < d.left ? lane : 0];
+        th = hits[d.h0 + ((uint32_t)lane < d.R ? (uint32_t)lane : 0u)].theta_t22;
     }
-    /* Votes of hit i that are near a bin edge (or all of them: forced) are queued for re-evaluation
-     * and their lanes redirected to the trash word. */
-    __device__ __forceinline__ static void queue_edge_votes(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl,
-                                                            SlowQueue &sq, uint32_t entry0, uint32_t hit, uint32_t left,
-                                                            bool forced, const uint32_t (&pos)[4], uint32_t (&addr)[4],
-                                                            int lane, uint32_t trash_addr)
+    /* returns the length of the wave's re-evaluation queue */
+    __device__ __forceinline__ uint32_t vote(const SlowCtx *scp, uint32_t *accp, const uint32_t *tblp, unsigned long long *qp,
+                                             uint32_t qn, const VoteStep &d, int lane) const
     {
-        uint32_t e = 4u * (uint32_t)lane;
-        asm volatile("" : "+v"(e));      /* keeps the compares below out of the vote loop's preamble */
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned long long nm = __ballot(e + j < left && (forced || pos[j] < PC_T24_EDGE));
-            if (nm) {
-                if (sq.n > SlowQueue::CAP - WAVE) sq.flush(sc, acc, tbl, lane);
-                sq.push(nm, lane, entry0 + e + j, hit);
-                if ((nm >> lane) & 1ull) addr[j] = trash_addr;
-            }
-        }
-    }
-    /* FULL: all 256 entries of the chunk exist, no lane needs the trash word.  FORCED: some hit of the
-     * run (or the whole bucket) carries the marker and has every vote re-evaluated; the common
-     * variant has no trace of that in its loop: readlane + 19 vector + compare/branch + 4 LDS atomics
-     * + loop control per hit (256 votes). */
-    template <bool FULL, bool FORCED>
-    __device__ __forceinline__ void vote_impl(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, SlowQueue &sq,
-                                              const VoteStep &d, int lane, unsigned long long fmask) const
-    {
+        lds_ctx *sc = (lds_ctx *)scp;
+        lds_u32 *acc = (lds_u32 *)accp, *tbl = (lds_u32 *)tblp;
+        lds_u64 *q = (lds_u64 *)qp;
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t24(th) << 8;     /* see vote_product */
-        const uint32_t acc_base = (uint32_t)(uintptr_t)(lds_u32 *)acc;        /* the accumulator's LDS address */
+        const uint32_t acc_base = (uint32_t)(uintptr_t)acc;  /* the accumulator's LDS address */
+        const uint32_t trash_addr = acc_base + 4u * (ACC_TRASH + (uint32_t)lane);
         uint32_t wa[4], rowb[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             wa[j] = w[j] << 10;                            /* 4 * theta_u, shifted like the hit base */
-            /* byte offset of the entry's accumulator row, or of the lane's trash word */
-            rowb[j] = (w[j] >> 15) & 0x1ff80u;
-            /* the partial variant issues its atomics from asm with absolute LDS addresses */
-            if (!FULL) rowb[j] = acc_base + (4u * (uint32_t)lane + j < d.left ? rowb[j] : 4u * (ACC_TRASH + (uint32_t)lane));
+            /* LDS address of the entry's accumulator row, or of the lane's trash word */
+            rowb[j] = 4u * (uint32_t)lane + j < d.left ? acc_base + ((w[j] >> 15) & 0x1ff80u) : trash_addr;
         }
-        const uint32_t trash_addr = (FULL ? 0u : acc_base) + 4u * (ACC_TRASH + (uint32_t)lane);
         /* lanes that hold at least one entry of this chunk */
-        const unsigned long long live = FULL ? ~0ull : __ballot(4u * (uint32_t)lane < d.left);
-        auto one_hit = [&](int i) {
-            const uint32_t csm = readlane_u(csmv, i);
+        const unsigned long long live = __ballot(4u * (uint32_t)lane < d.left);
+#ifdef VOTE_DIAG_NOLOOP                 /* timing-only build: steps and loads without the votes */
+        asm volatile("" ::"v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(csmv), "s"(live));
+        return qn;
+#endif
+        for (uint32_t i = d.i0; i < d.i1; i++) {
+            const uint32_t csm = readlane_u(csmv, (int)i);
             uint32_t addr[4], pos[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -525,44 +525,45 @@ struct VoteRegs {
                  * of an edge.  One compare of the smallest of the four decides whether anything is
                  * queued; lanes past the bucket end only ever cause a look that finds nothing. */
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
-                const bool forced = FORCED && ((fmask >> i) & 1ull);
-                if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE) || forced, 0))
-                    queue_edge_votes(sc, acc, tbl, sq, d.e0, d.h0 + (uint32_t)i, d.left, forced, pos, addr, lane, trash_addr);
+                if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE), 0)) {
+                    /* queued for re-evaluation, their lanes redirected to the trash word.  One rolled loop
+                     * over the four entries of a lane: this block is cold and exists once per copy of the
+                     * vote loop, with the queue's flush inlined (a call would make the register allocator
+                     * spill around the whole loop) */
+                    uint32_t e = 4u * (uint32_t)lane;
+                    asm volatile("" : "+v"(e));
+#pragma nounroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t pj = j == 0 ? pos[0] : j == 1 ? pos[1] : j == 2 ? pos[2] : pos[3];
+                        const unsigned long long nm = __ballot(e + (uint32_t)j < d.left && pj < PC_T24_EDGE);
+                        if (nm) {
+                            qn = slow_push(sc, acc, tbl, q, qn, nm, d.e0 + e + (uint32_t)j, d.h0 + i, lane);
+                            const bool me = (nm >> lane) & 1ull;
+                            addr[0] = me && j == 0 ? trash_addr : addr[0];
+                            addr[1] = me && j == 1 ? trash_addr : addr[1];
+                            addr[2] = me && j == 2 ? trash_addr : addr[2];
+                            addr[3] = me && j == 3 ? trash_addr : addr[3];
+                        }
+                    }
+                }
             }
-            if (FULL) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(acc) + addr[j]), 1u);
-            } else {
-                /* A chunk that is not full: the atomics are issued for the lanes that hold entries only
-                 * (EXEC narrowed around them), so the idle lanes cost no LDS cycles and cause no bank
-                 * conflicts; the one lane that holds fewer than four entries sends the rest to its
-                 * trash word.  Written in asm because the compiler has no way to say this; the
-                 * workgroup waits for these atomics (lgkmcnt) before it reads the accumulator. */
-                unsigned long long saved;
-                asm volatile("s_mov_b64 %0, exec\n\t"
-                             "s_mov_b64 exec, %1\n\t"
-                             "ds_add_u32 %2, %6\n\t"
-                             "ds_add_u32 %3, %6\n\t"
-                             "ds_add_u32 %4, %6\n\t"
-                             "ds_add_u32 %5, %6\n\t"
-                             "s_mov_b64 exec, %0"
-                             : "=&s"(saved)
-                             : "s"(live), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(1u)
-                             : "memory");
-            }
-        };
-        for (int i = d.i0; i < d.i1; i++) one_hit(i);
-    }
-    __device__ __forceinline__ void vote(const SlowCtx *sc, uint32_t *acc, const uint32_t *tbl, SlowQueue &sq,
-                                         const VoteStep &d, int lane) const
-    {
-        /* hits whose every vote is re-evaluated: all of them when the bucket holds a marker */
-        const unsigned long long fmask =
-            MODE == 0 ? (d.bforced ? ~0ull : __ballot(th == PC_T22_FORCE) & ((2ull << (d.R - 1u)) - 1ull)) : 0ull;
-        if (MODE == 0 && fmask) vote_impl<false, true>(sc, acc, tbl, sq, d, lane, fmask);
-        else if (d.left >= 4u * WAVE) vote_impl<true, false>(sc, acc, tbl, sq, d, lane, 0ull);
-        else vote_impl<false, false>(sc, acc, tbl, sq, d, lane, 0ull);
+#ifdef VOTE_DIAG_NOATOM             /* timing-only build: the vote arithmetic without the LDS atomics */
+            asm volatile("" ::"v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]));
+            continue;
+#endif
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %0, exec\n\t"
+                         "s_mov_b64 exec, %1\n\t"
+                         "ds_add_u32 %2, %6\n\t"
+                         "ds_add_u32 %3, %6\n\t"
+                         "ds_add_u32 %4, %6\n\t"
+                         "ds_add_u32 %5, %6\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(saved)
+                         : "s"(live), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(1u)
+                         : "memory");
+        }
+        return qn;
     }
 };
 
@@ -712,8 +713,8 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
  * table: log2(ucap) bits instead of 32), so that hits that share a bucket are adjacent (on the bench
  * scene a bucket is hit 3.8 times per reference point on average; streaming it once per run cuts
  * the entry traffic 4.7x), and writes the run list the vote kernel works from:
- * runs[u] = {slot | (hits - 1) << 26, index of the run's first hit}; a run also ends at every
- * multiple of 64 hits, so a run is at most one hit per lane.
+ * runs[u] = {slot | (hits - 1) << 26, index of the run's first hit | marker << 31}; a run also ends
+ * at every multiple of 64 hits, so a run is at most one hit per lane.
  * One workgroup per reference point: radix sort of (slot, index) in LDS -- rocPRIM's block
  * primitive (DESIGN.md 4 says why it stays) -- then the payloads are gathered into the second list.
  * A list longer than SORT_MAX is sorted in segments of SORT_MAX hits (a key then has one run per
@@ -747,9 +748,14 @@ __device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_
         idx[k] = i;
     }
     SORT().sort(key, idx, s_sort, 0u, bits);
+    uint32_t marked = 0;                 /* sorted positions of this thread whose hit carries the marker */
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
-        if (i0 + k < n) dst[i0 + k] = spay[idx[k]];
+        if (i0 + k < n) {
+            const oslamk_pay py = spay[idx[k]];
+            dst[i0 + k] = py;
+            marked |= (uint32_t)(py.theta_t22 == PC_T22_FORCE) << k;
+        }
     s_last[tid] = key[ITEMS - 1];
     __syncthreads();
     uint32_t heads = 0, cnt = 0;
@@ -777,6 +783,7 @@ __device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_
         if (w < wid) pos += v;
         total += v;
     }
+    const uint32_t pos0 = pos;          /* index of this thread's first head; the run before it holds its leading positions */
 #pragma unroll
     for (int k = 0; k < ITEMS; k++)
         if ((heads >> k) & 1u) {
@@ -787,10 +794,19 @@ __device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_
         }
     __threadfence_block();
     __syncthreads();                    /* the run heads are written; the LDS arrays are reused by the next segment */
+    /* bit 31 of `first`: some hit of the run carries the marker (rare: degenerate geometry) */
+    if (marked) {
+        uint32_t ri = pos0 - 1u;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            ri += (heads >> k) & 1u;
+            if ((marked >> k) & 1u) atomicOr(&runs[ri].first, 0x80000000u);
+        }
+    }
     /* length of every run = distance to the next head (or to the end of the segment) */
     for (uint32_t u = (uint32_t)tid; u < total; u += SORT_THREADS) {
-        const uint32_t f0 = runs[n_runs + u].first;
-        const uint32_t f1 = u + 1 < total ? runs[n_runs + u + 1].first : seg + n;
+        const uint32_t f0 = runs[n_runs + u].first & 0x7fffffffu;
+        const uint32_t f1 = u + 1 < total ? runs[n_runs + u + 1].first & 0x7fffffffu : seg + n;
         runs[n_runs + u].slot_r |= (f1 - f0 - 1u) << OSLAMK_RUN_SHIFT;
     }
     return total;
@@ -838,19 +854,27 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
  *     surfaces hold 10^4 entries) are queued in LDS.
  *   - Giants first: cut into units of one chunk x at most 16-32 hits, dealt round-robin to the
  *     16 waves.
- *   - Then the rest, dynamically: a wave takes VOTE_BLOCK runs at a time from a counter in LDS
- *     (descriptors of the block after the current one are in flight) and skips the giants.
- * No barrier between the two; the waves meet at the end.  The loads of the step after the one
- * being voted are in flight.
+ *   - Then the rest, dynamically: a wave takes VOTE_BLOCK runs at a time from a counter in LDS and
+ *     skips the giants; the run records of the block two ahead and the bucket records of the next
+ *     one are in flight.
+ * No barrier between the two; the waves meet at the end.
+ * The entry stream (200 GB per 5k x 100k registration, from the Infinity Cache and HBM) is what
+ * has to be kept busy: with one step's loads in flight per wave the kernel sat at the latency of a
+ * load per step (59 of 89 ms with the votes compiled out).  So a wave works in groups of VOTE_GROUP
+ * steps: their descriptors first, then all their loads back to back (16 B per lane each), then the
+ * votes, one copy of the vote loop per member so that each waits for its own registers only.
  * Workgroups b and b + 8 share an XCD (speed only): the slices of one reference point are placed
  * on one XCD, so its hit and run lists reach one L2 once.
  * ------------------------------------------------------------------------*/
 #define VOTE_QCAP 1024
 #ifndef VOTE_BLOCK
-#define VOTE_BLOCK 8
+#define VOTE_BLOCK 16
 #endif
 #ifndef VOTE_GIANT
 #define VOTE_GIANT 32
+#endif
+#ifndef VOTE_GROUP
+#define VOTE_GROUP 4
 #endif
 #define RUN_SLOT_MASK ((1u << OSLAMK_RUN_SHIFT) - 1u)
 
@@ -865,7 +889,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     __shared__ uint32_t s_tbl[32];
     __shared__ uint32_t s_q[VOTE_QCAP];
     __shared__ SlowCtx s_ctx;
-    __shared__ unsigned long long s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SlowQueue::CAP : 1];
+    __shared__ unsigned long long s_slow[MODE == 0 ? (VOTE_THREADS / WAVE) * SLOW_CAP : 1];
 
     typedef VoteRegs<MODE> VR;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
@@ -898,9 +922,8 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
 
     unsigned long long my_votes = 0;
-    SlowQueue sq;
-    sq.q = s_slow + (MODE == 0 ? wid * SlowQueue::CAP : 0);
-    sq.n = 0;
+    unsigned long long *sq = s_slow + (MODE == 0 ? wid * SLOW_CAP : 0);   /* this wave's re-evaluation queue */
+    uint32_t sq_n = 0;
 #ifdef VOTE_PROF
     const long long pt0 = clock64();
 #endif
@@ -917,10 +940,12 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             const uint32_t k = k0 + (uint32_t)tid;
             bool giant = false;
             if (k < n_runs) {
-                const uint32_t sr = runs[k].slot_r;
-                const uint32_t ln = uinfo[sr & RUN_SLOT_MASK].len & 0x7fffffffu, R = (sr >> OSLAMK_RUN_SHIFT) + 1u;
+                const oslamk_run rr = runs[k];
+                const uint32_t lf = uinfo[rr.slot_r & RUN_SLOT_MASK].len;
+                const uint32_t ln = lf & 0x7fffffffu, R = (rr.slot_r >> OSLAMK_RUN_SHIFT) + 1u;
                 if (first) my_votes += (unsigned long long)ln * R;
-                giant = ((ln + 255u) >> 8) * R > T;
+                /* items with a marker (MODE 0) are neither giants nor small items: they wait for the pass after the loop */
+                giant = ((ln + 255u) >> 8) * R > T && !(MODE == 0 && ((lf | rr.first) >> 31));
             }
             const unsigned long long gm = __ballot(giant);
             if (gm) {
@@ -931,7 +956,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                 if (giant && p < VOTE_QCAP) s_q[p] = k;
             }
         }
-        __syncthreads();            /* also: acc zeroed, s_tbl written */
+        __syncthreads();            /* also: acc zeroed, s_tbl and s_ctx written */
         if (s_qn <= VOTE_QCAP) break;
         T *= 2;                     /* more giants than the queue holds: a higher bar, same for every thread */
         __syncthreads();
@@ -939,169 +964,180 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const uint32_t n_q = uni_u32(s_qn);
     T = uni_u32(T);
 
-    /* ---- the step generator of this wave; all state wave-uniform except the windows ---- */
-    const uint32_t n_blocks = (n_runs + VOTE_BLOCK - 1) / VOTE_BLOCK;
-    uint2 cur_ru = make_uint2(0, 0), cur_inf = make_uint2(0, 0), nxt_ru, nxt_inf;   /* lanes < VOTE_BLOCK: {slot_r, first}, {start, len} */
-    uint32_t cur_b, nxt_b;
-    auto grab = [&]() -> uint32_t {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s_next, 1u);
-        return uni_u32(readlane_u(b, 0));
+    /* ---- the work of this wave, as windows of up to 64 step descriptors made lane-parallel ----
+     * A set of items sits one per lane: bucket start, length, first hit, hits, and the number of units the
+     * item is cut into (chunks, times 1, 2 or 4 ranges of hits for a giant).  The wave takes the units
+     * u0, u0 + stride, ... of the set: lane i of a window looks its unit up in the running sums of the set
+     * (binary search across lanes with ds_bpermute) and computes the step {first entry, entries left,
+     * first hit, hits, hit range} -- about one instruction per step instead of a scalar generator of ~60.
+     * The steps of a window are then voted in groups of VOTE_GROUP: descriptors to scalar registers,
+     * all the group's loads back to back (16 B per lane each), the votes, one copy of the vote loop
+     * per member so that each waits for its own registers only. */
+    uint32_t I_st = 0, I_ln = 0, I_h0 = 0, I_misc = 0, I_nu = 0, I_incl = 0;      /* the set: one item per lane */
+    auto bperm = [&](uint32_t from_lane, uint32_t v) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
     };
-    auto fetch = [&](uint32_t b, uint2 &ru, uint2 &inf) {
-        const uint32_t k = b * VOTE_BLOCK + (uint32_t)lane;
-        ru = make_uint2(0, 0);
-        inf = make_uint2(0, 0);
-        if (lane < VOTE_BLOCK && k < n_runs) {
-            const oslamk_run rr = runs[k];
-            const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
-            ru = make_uint2(rr.slot_r, rr.first);
-            inf = make_uint2(ui.start, ui.len);
+    /* votes the units u0, u0 + stride, ... < total of the current set */
+    auto vote_set = [&](uint32_t u0, uint32_t stride) {
+        uint32_t incl = I_nu;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
         }
-    };
-    /* the items of the current block this wave votes: present in the slice and not a giant */
-    auto examine = [&]() -> unsigned long long {
-        const uint32_t ln = cur_inf.y & 0x7fffffffu, R = (cur_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
-        return __ballot(ln != 0u && ((ln + 255u) >> 8) * R <= T);
-    };
-    cur_b = grab();
-    fetch(cur_b, cur_ru, cur_inf);
-    nxt_b = grab();
-    fetch(nxt_b, nxt_ru, nxt_inf);
-
-    /* giants: window of 64 queued items, one per lane */
-    uint32_t g_tw = 0, g_base = 0, g_tot = 0, g_u = uni_u32((uint32_t)wid);
-    uint2 gw_ru = make_uint2(0, 0), gw_inf = make_uint2(0, 0);
-    uint32_t gw_incl = 0, gw_nu = 0;
-    bool giants = n_q != 0;
-    /* small items */
-    unsigned long long s_m = 0;
-    bool s_open = false;
-    uint32_t it_st = 0, it_ln = 0, it_h0 = 0, it_R = 1, it_C = 0, it_c = 0;
-    bool it_bf = false;
-
-    auto next_step = [&]() -> VoteStep {
-        VoteStep d;
-        d.valid = false;
-        for (;;) {
-            if (giants) {
-                if (g_u < g_base + g_tot) {
-                    const unsigned long long m = __ballot(g_base + gw_incl > g_u);   /* a suffix of the lanes */
-                    const int tl = __ffsll((long long)m) - 1;
-                    const uint32_t excl = readlane_u(gw_incl - gw_nu, tl);
-                    const uint32_t sr = readlane_u(gw_ru.x, tl), lf = readlane_u(gw_inf.y, tl);
-                    const uint32_t ln = lf & 0x7fffffffu, R = (sr >> OSLAMK_RUN_SHIFT) + 1u;
-                    const uint32_t lg = R > 32u ? 2u : R > 16u ? 1u : 0u;          /* the hits of a chunk in 1, 2 or 4 units */
-                    const uint32_t local = g_u - g_base - excl, c = local >> lg, hs = local & ((1u << lg) - 1u);
-                    const uint32_t per = (R + (1u << lg) - 1u) >> lg;
-                    d.e0 = readlane_u(gw_inf.x, tl) + (c << 8);
-                    d.left = ln - (c << 8);
-                    d.h0 = readlane_u(gw_ru.y, tl);
-                    d.R = R;
-                    d.i0 = (int)(hs * per);
-                    d.i1 = (int)(hs * per + per < R ? hs * per + per : R);
-                    d.bforced = (lf >> 31) != 0;
-                    d.valid = true;
-                    g_u += VOTE_THREADS / WAVE;
-                    return d;
+        I_incl = incl;
+        const uint32_t total = readlane_u(incl, WAVE - 1);
+        for (uint32_t ub = u0; ub < total; ub += stride * WAVE) {
+            /* ---- the window: lane i <-> unit ub + stride * i ---- */
+            const uint32_t u = ub + stride * (uint32_t)lane;
+            const bool act = u < total;
+            uint32_t lo = 0;                                   /* items whose running sum is <= u: the unit's item */
+#pragma unroll
+            for (uint32_t s2 = WAVE / 2; s2 > 0; s2 >>= 1) lo += bperm(lo + s2 - 1u, I_incl) <= u ? s2 : 0u;
+            lo = lo < (uint32_t)WAVE - 1u ? lo : (uint32_t)WAVE - 1u;
+            const uint32_t st = bperm(lo, I_st), ln = bperm(lo, I_ln), h0 = bperm(lo, I_h0), mi = bperm(lo, I_misc);
+            const uint32_t local = u - (bperm(lo, I_incl) - bperm(lo, I_nu));
+            const uint32_t R = (mi & 63u) + 1u, lg = mi >> 6;
+            const uint32_t c = local >> lg, hs = local & ((1u << lg) - 1u), per = (R + (1u << lg) - 1u) >> lg;
+            const uint32_t i0 = hs * per, i1 = i0 + per < R ? i0 + per : R;
+            /* a lane past the end describes a step that loads entry 0 and hit 0 and votes nothing */
+            const uint32_t w_e0 = act ? st + (c << 8) : 0u, w_left = act ? ln - (c << 8) : 0u, w_h0 = act ? h0 : 0u,
+                           w_misc = act ? (R - 1u) | (i0 << 6) | (i1 << 13) : 0u;
+            const uint32_t rest = (total - ub + stride - 1u) / stride, n_w = rest < (uint32_t)WAVE ? rest : (uint32_t)WAVE;
+            for (uint32_t g0 = 0; g0 < n_w; g0 += VOTE_GROUP) {
+                VR regs[VOTE_GROUP];
+                VoteStep ds[VOTE_GROUP];
+#pragma unroll
+                for (int g = 0; g < VOTE_GROUP; g++) {
+                    const int l = (int)((g0 + g) & (WAVE - 1));           /* past 63 only in the last group: any lane past n_w */
+                    const bool in = g0 + g < n_w;
+                    const uint32_t misc = in ? readlane_u(w_misc, l) : 0u;
+                    ds[g].e0 = in ? readlane_u(w_e0, l) : 0u;
+                    ds[g].left = in ? readlane_u(w_left, l) : 0u;
+                    ds[g].h0 = in ? readlane_u(w_h0, l) : 0u;
+                    ds[g].R = (misc & 63u) + 1u;
+                    ds[g].i0 = (misc >> 6) & 127u;
+                    ds[g].i1 = (misc >> 13) & 127u;
+                    ds[g].valid = true;
+                    regs[g].load(e4, hits, ds[g], lane);
                 }
-                g_base += g_tot;
-                g_tot = 0;
-                if (g_tw >= n_q) {
-                    giants = false;
-                    continue;
-                }
-                {
-                    const uint32_t t = g_tw + (uint32_t)lane;
-                    gw_ru = make_uint2(0, 0);
-                    gw_inf = make_uint2(0, 0);
-                    gw_nu = 0;
-                    if (t < n_q) {
-                        const oslamk_run rr = runs[s_q[t]];
-                        const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
-                        const uint32_t R = (rr.slot_r >> OSLAMK_RUN_SHIFT) + 1u;
-                        gw_ru = make_uint2(rr.slot_r, rr.first);
-                        gw_inf = make_uint2(ui.start, ui.len);
-                        gw_nu = (((ui.len & 0x7fffffffu) + 255u) >> 8) << (R > 32u ? 2u : R > 16u ? 1u : 0u);
-                    }
-                    uint32_t incl = gw_nu;
-                    for (int o = 1; o < WAVE; o <<= 1) {
-                        const uint32_t up = __shfl_up(incl, o, WAVE);
-                        if (lane >= o) incl += up;
-                    }
-                    gw_incl = incl;
-                    g_tot = readlane_u(incl, WAVE - 1);
-                    g_tw += WAVE;
-                }
-                continue;
-            }
-            if (it_c < it_C) {
-                const uint32_t o = it_c << 8;
-                d.e0 = it_st + o;
-                d.left = it_ln - o;
-                d.h0 = it_h0;
-                d.R = it_R;
-                d.i0 = 0;
-                d.i1 = (int)it_R;
-                d.bforced = it_bf;
-                d.valid = true;
-                it_c++;
-                return d;
-            }
-            if (!s_open) {                        /* first look at the first block */
-                s_open = true;
-                s_m = cur_b < n_blocks ? examine() : 0ull;
-            }
-            while (s_m == 0ull) {
-                if (cur_b >= n_blocks) return d;  /* this wave is done (the counter only grows) */
-                cur_ru = nxt_ru;
-                cur_inf = nxt_inf;
-                cur_b = nxt_b;
-                if (cur_b >= n_blocks) return d;
-                nxt_b = grab();
-                fetch(nxt_b, nxt_ru, nxt_inf);
-                s_m = examine();
-            }
-            {
-                const int j = __ffsll((long long)s_m) - 1;
-                s_m &= s_m - 1ull;
-                const uint32_t sr = readlane_u(cur_ru.x, j), lf = readlane_u(cur_inf.y, j);
-                it_st = readlane_u(cur_inf.x, j);
-                it_ln = lf & 0x7fffffffu;
-                it_bf = (lf >> 31) != 0;
-                it_h0 = readlane_u(cur_ru.y, j);
-                it_R = (sr >> OSLAMK_RUN_SHIFT) + 1u;
-                it_C = (it_ln + 255u) >> 8;
-                it_c = 0;
+                asm volatile("" ::: "memory");      /* all the group's loads are issued here, in this order: none sinks into its vote */
+#pragma unroll
+                for (int g = 0; g < VOTE_GROUP; g++) sq_n = regs[g].vote(sc, acc, s_tbl, sq, sq_n, ds[g], lane);
             }
         }
     };
+    /* item of a lane from its run and bucket records; units = chunks << lg (0 = not voted here) */
+    auto set_item = [&](const uint2 &ru, const uint2 &inf, bool take, uint32_t lg) {
+        const uint32_t ln = inf.y & 0x7fffffffu, R = (ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+        I_st = inf.x;
+        I_ln = ln;
+        I_h0 = ru.y & 0x7fffffffu;
+        I_misc = (R - 1u) | (lg << 6);
+        I_nu = take ? ((ln + 255u) >> 8) << lg : 0u;
+    };
+    auto marked = [&](const uint2 &ru, const uint2 &inf) -> bool { return MODE == 0 && ((inf.y | ru.y) >> 31); };
 
-    /* ---- voting: the loads of the next step are in flight while a step is voted ---- */
+    /* ---- the sets, one after the other (one call site of vote_set: its vote loops exist once) ----
+     * giants first: 64 queued items at a time, their units dealt round-robin to the waves;
+     * then the rest, dynamically: VOTE_BLOCK runs at a time from a counter in LDS; the run records of the
+     * block two ahead and the bucket records of the next one are in flight */
     {
-        VR rA, rB;
-        VoteStep dA = next_step(), dB;
-        if (dA.valid) rA.load(e4, hits, dA, lane);
-        while (dA.valid) {
-            dB = next_step();
-            if (dB.valid) rB.load(e4, hits, dB, lane);
-            rA.vote(sc, acc, s_tbl, sq, dA, lane);
-#ifdef VOTE_AB
-            if (!dB.valid) break;
-            dA = next_step();
-            if (dA.valid) rA.load(e4, hits, dA, lane);
-            rB.vote(sc, acc, s_tbl, sq, dB, lane);
-#else
-            rA = rB;
-            dA = dB;
-#endif
+        const uint32_t n_blocks = (n_runs + VOTE_BLOCK - 1) / VOTE_BLOCK;
+        auto grab = [&]() -> uint32_t {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(&s_next, 1u);
+            return uni_u32(readlane_u(b, 0));
+        };
+        auto fetch_runs = [&](uint32_t b) -> uint2 {
+            const uint32_t k = b * VOTE_BLOCK + (uint32_t)lane;
+            uint2 ru = make_uint2(0, 0);
+            if (lane < VOTE_BLOCK && k < n_runs) {
+                const oslamk_run rr = runs[k];
+                ru = make_uint2(rr.slot_r, rr.first);
+            }
+            return ru;
+        };
+        auto fetch_info = [&](uint32_t b, const uint2 &ru) -> uint2 {
+            const uint32_t k = b * VOTE_BLOCK + (uint32_t)lane;
+            uint2 inf = make_uint2(0, 0);
+            if (lane < VOTE_BLOCK && k < n_runs) {
+                const oslamk_uinfo ui = uinfo[ru.x & RUN_SLOT_MASK];
+                inf = make_uint2(ui.start, ui.len);
+            }
+            return inf;
+        };
+        uint32_t cur_b = grab();
+        uint2 cur_ru = fetch_runs(cur_b);
+        uint32_t nx1_b = grab();
+        uint2 nx1_ru = fetch_runs(nx1_b);
+        uint32_t nx2_b = grab();
+        uint2 nx2_ru = fetch_runs(nx2_b);
+        uint2 cur_inf = fetch_info(cur_b, cur_ru);
+        uint2 nx1_inf = fetch_info(nx1_b, nx1_ru);
+        uint32_t tw = 0;                                 /* giants: first queue entry of the next set */
+        for (;;) {
+            uint32_t u0, stride;
+            if (tw < n_q) {
+                const uint32_t t = tw + (uint32_t)lane;
+                uint2 ru = make_uint2(0, 0), inf = make_uint2(0, 0);
+                if (t < n_q) {
+                    const oslamk_run rr = runs[s_q[t]];
+                    const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
+                    ru = make_uint2(rr.slot_r, rr.first);
+                    inf = make_uint2(ui.start, ui.len);
+                }
+                const uint32_t R = (ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+                set_item(ru, inf, t < n_q, R > 32u ? 2u : R > 16u ? 1u : 0u);      /* the hits of a chunk in 1, 2 or 4 units */
+                tw += WAVE;
+                u0 = uni_u32((uint32_t)wid);
+                stride = VOTE_THREADS / WAVE;
+            } else {
+                if (cur_b >= n_blocks) break;            /* the counter only grows: this wave is done */
+                const uint32_t ln = cur_inf.y & 0x7fffffffu, R = (cur_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+                /* present in the slice, not a giant (those are done), no marker (those come last) */
+                set_item(cur_ru, cur_inf, ln != 0u && ((ln + 255u) >> 8) * R <= T && !marked(cur_ru, cur_inf), 0u);
+                /* the next blocks move up before the votes, so that their loads fly meanwhile */
+                cur_ru = nx1_ru;
+                cur_inf = nx1_inf;
+                cur_b = nx1_b;
+                nx1_ru = nx2_ru;
+                nx1_b = nx2_b;
+                nx1_inf = fetch_info(nx1_b, nx1_ru);
+                nx2_b = grab();
+                nx2_ru = fetch_runs(nx2_b);
+                u0 = 0u;
+                stride = 1u;
+            }
+            vote_set(u0, stride);
         }
     }
-    if (MODE == 0) sq.flush(sc, acc, s_tbl, lane);
+    if (MODE == 0) {
+        /* the items with a marker, dealt round-robin to the waves: every vote through the queue */
+        for (uint32_t k0 = (uint32_t)wid * WAVE; k0 < n_runs; k0 += VOTE_THREADS) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            oslamk_run rr;
+            oslamk_uinfo ui;
+            rr.slot_r = rr.first = 0;
+            ui.start = ui.len = 0;
+            if (k < n_runs) {
+                rr = runs[k];
+                ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
+            }
+            unsigned long long fm = __ballot((ui.len & 0x7fffffffu) != 0u && ((ui.len | rr.first) >> 31));
+            while (fm) {
+                const int j = __ffsll((long long)fm) - 1;
+                fm &= fm - 1ull;
+                sq_n = forced_item((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, readlane_u(ui.start, j),
+                                   readlane_u(ui.len, j) & 0x7fffffffu, readlane_u(rr.first, j) & 0x7fffffffu,
+                                   (readlane_u(rr.slot_r, j) >> OSLAMK_RUN_SHIFT) + 1u, lane);
+            }
+        }
+        if (sq_n) slow_queue_flush((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, lane);
+    }
 #ifdef VOTE_PROF
     const long long pt1 = clock64();
 #endif
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the atomics issued from asm (VoteRegs::vote_impl) */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the atomics issued from asm (VoteRegs::vote) */
     __syncthreads();
 #ifdef VOTE_PROF
     const long long pt2 = clock64();
