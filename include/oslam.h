@@ -253,8 +253,8 @@ int oslam_model_keys(oslam_model *m, size_t ref_index, uint32_t *keys_out);
  * bucket size in *count_out and copies at most cap indices. */
 int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t cap,
                        size_t *count_out);
-/* The stored words (m_r - 1024*slice) << 22 | theta_u of one key's bucket in one table slice, in
- * storage order (what a vote wave streams, 4 consecutive words per lane). */
+/* The stored words theta_u << 10 | (m_r - 1023*slice) of one key's bucket in one table slice (slices hold
+ * 1023 model reference points), in storage order (what a vote wave streams, 4 consecutive words per lane). */
 int oslam_model_bucket_words(oslam_model *m, uint32_t key, int slice, uint32_t *words_out, size_t cap,
                              size_t *count_out);
 /* Dense accumulator acc[M][32] of scene reference point ref_index after voting. */

@@ -430,6 +430,8 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
     if (m->params.vote_mode != OSLAM_VOTE_FAST)
         HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
+    /* every word a padding entry until the fill pass writes it: padding votes into the accumulator's sink row */
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->ent.e4, (int)PC_ROW_SINK, n_pairs + 256, (hipStream_t)g_stream));
     KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->ent, g_stream));
     if (!getenv("OSLAM_NO_SPREAD")) KCHK(oslamk_bucket_spread(m->table, m->ent, g_stream));   /* the switch is for A/B measurements */
     rc = build_uinfo(m);
@@ -456,7 +458,8 @@ done:
 static int build_uinfo(oslam_model *m);
 
 #define OSLAM_DB_MAGIC 0x4c444d4f534c4f00ull     /* "\0OLSOMDL" */
-#define OSLAM_DB_VERSION 4u                      /* table layout: 16-B slots, e4 = m_r<<22 | theta (2^-22 turn); checksum covers the header */
+#define OSLAM_DB_VERSION 5u                      /* table layout: 16-B slots, slices of 1023 points, e4 = theta (2^-22 turn) << 10 | row, padding
+                                                  * words = row 1023; checksum covers the header */
 typedef struct db_header {
     uint64_t magic;
     uint32_t version, vote_mode;
@@ -652,6 +655,8 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
     if (hd.has_uv) HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
     HIPCHK(hipMemcpy(m->table.slots, h_slots, sizeof(oslamk_slot) * n_slots, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->ent.e4, (int)PC_ROW_SINK, n_pairs + 256, (hipStream_t)g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
     rc = db_read_dev(f, m->table.ukeys, sizeof(uint32_t) * (size_t)hd.ucap, &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.e4, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
@@ -1825,7 +1830,7 @@ int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t
                 HIPCHK(hipMemcpy(tmi, m->ent.mi + tab[slot].start, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
                 for (e = 0; e < len; e++, total++)
                     if (pairs_out && written < cap)
-                        pairs_out[written++] = ((uint32_t)s * OSLAMK_SLICE + (tmp[e] >> 22)) * (uint32_t)m->c.n + tmi[e];
+                        pairs_out[written++] = ((uint32_t)s * OSLAMK_SLICE + (tmp[e] & PC_ROW_MASK)) * (uint32_t)m->c.n + tmi[e];
                 break;
             }
             if (tab[slot].key == 0) break;

@@ -14,7 +14,8 @@
 extern "C" {
 #endif
 
-#define OSLAMK_SLICE 1024      /* model reference points per table slice / LDS accumulator */
+#define OSLAMK_SLICE 1023      /* model reference points per table slice */
+#define OSLAMK_ROWS 1024       /* rows of the LDS accumulator: one per reference point of the slice + the sink row of padding entries */
 #define OSLAMK_NBIN 32         /* alpha bins per accumulator row (reference uses 0..30) */
 
 /* One slot of a slice's open-addressing table, keyed by the 32-bit PPF key. */
@@ -27,8 +28,9 @@ typedef struct oslamk_slot {
 
 /* Model pair entries, bucketed by (slice, key); every bucket starts on a multiple of 4
  * entries so that a lane can fetch 4 of them with one 16-byte load.
- *   e4[e] = (m_r - slice*OSLAMK_SLICE) << 22 | theta_u   the 4 bytes a vote streams
- *           (theta_u = pc_angle_t22 of (T_m_g * m_i).y/.z, kernel.cu:330-332)
+ *   e4[e] = theta_u << 10 | (m_r - slice*OSLAMK_SLICE)   the 4 bytes a vote streams (pc_entry_word;
+ *           theta_u = pc_angle_t22 of (T_m_g * m_i).y/.z, kernel.cu:330-332); the up to 3 padding
+ *           words behind a bucket hold row 1023, the accumulator's sink row
  *   uv[e] = (T_m_g * m_i).y/.z as floats: read only by the rare votes that are
  *           re-evaluated with the reference's own arithmetic (exact mode)
  *   mi[e] = m_i (parity tap only) */

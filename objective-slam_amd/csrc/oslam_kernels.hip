@@ -40,7 +40,8 @@
 
 #define WAVE 64
 #define VOTE_THREADS 1024
-#define ACC_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)
+#define ACC_CELLS (OSLAMK_ROWS * OSLAMK_NBIN)
+#define ACC_REAL_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)      /* without the sink row */
 
 /* thresholds of pc_alpha_bin_table(); every vote workgroup copies them into LDS */
 __device__ const uint32_t k_alpha_thr[32] = {PC_ALPHA_THR_FLAT};
@@ -234,7 +235,7 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
         const uint32_t th = pc_angle_t22(uy, uz);
         /* a marker forces the whole bucket through the exact path: flagged in bit 31 of the cursor */
         if (th == PC_T22_FORCE) atomicOr(&tab[slot].cur, 0x80000000u);
-        ent.e4[e] = ((uint32_t)(m_r - slice * OSLAMK_SLICE) << 22) | (th == PC_T22_FORCE ? 0u : th);
+        ent.e4[e] = pc_entry_word(th == PC_T22_FORCE ? 0u : th, (uint32_t)(m_r - slice * OSLAMK_SLICE));
     }
     ent.mi[e] = (uint16_t)i;
     if (ent.uv) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_bucket_spread(oslamk_table t
                 s_e4[i] = w;
                 if (ent.uv) s_uv[i] = ent.uv[base + i];
                 s_mi[i] = ent.mi[base + i];
-                key[i] = ((unsigned long long)(w & 0x3fffffu) << 32) | i;
+                key[i] = ((unsigned long long)(w >> PC_ROW_BITS) << 32) | i;
             } else {
                 key[i] = ~0ull;
             }
@@ -416,7 +417,7 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
         if (base + lane < n) {
             const unsigned long long it = q[base + lane];
             const uint32_t entry = (uint32_t)it;
-            const uint32_t mr = sc->e4[entry] >> 22;
+            const uint32_t mr = sc->e4[entry] & PC_ROW_MASK;
             const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
             const uint32_t i = sc->hits[(uint32_t)(it >> 32)].idx;
             const float x = sc->px[i], y = sc->py[i], z = sc->pz[i];
@@ -494,17 +495,15 @@ struct VoteRegs {
         lds_ctx *sc = (lds_ctx *)scp;
         lds_u32 *acc = (lds_u32 *)accp, *tbl = (lds_u32 *)tblp;
         lds_u64 *q = (lds_u64 *)qp;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t csmv = pc_vote_base_t24(th) << 8;     /* see vote_product */
+        /* the entry words as they are: theta_u << 10 | row (pc_entry_word); lanes and words past the end of
+         * the bucket are masked out of the atomics (EXEC) or are padding entries that vote into the sink row */
+        const uint32_t wa[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t csmv = pc_vote_base_t32(th);
         const uint32_t acc_base = (uint32_t)(uintptr_t)acc;  /* the accumulator's LDS address */
         const uint32_t trash_addr = acc_base + 4u * (ACC_TRASH + (uint32_t)lane);
-        uint32_t wa[4], rowb[4];
+        uint32_t rowb[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            wa[j] = w[j] << 10;                            /* 4 * theta_u, shifted like the hit base */
-            /* LDS address of the entry's accumulator row, or of the lane's trash word */
-            rowb[j] = 4u * (uint32_t)lane + j < d.left ? acc_base + ((w[j] >> 15) & 0x1ff80u) : trash_addr;
-        }
+        for (int j = 0; j < 4; j++) rowb[j] = acc_base + ((wa[j] & PC_ROW_MASK) << 7);     /* LDS address of the entry's row */
         /* lanes that hold at least one entry of this chunk */
         const unsigned long long live = __ballot(4u * (uint32_t)lane < d.left);
 #ifdef VOTE_DIAG_NOLOOP                 /* timing-only build: steps and loads without the votes */
@@ -874,7 +873,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 #define VOTE_GIANT 32
 #endif
 #ifndef VOTE_GROUP
-#define VOTE_GROUP 4
+#define VOTE_GROUP 4           /* must divide 64 */
 #endif
 #define RUN_SLOT_MASK ((1u << OSLAMK_RUN_SHIFT) - 1u)
 
@@ -977,6 +976,20 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     auto bperm = [&](uint32_t from_lane, uint32_t v) -> uint32_t {
         return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
     };
+    /* step g of a window: its descriptor from lane g of the window's registers (VOTE_GROUP divides 64, so a
+     * group never runs past lane 63; lanes past the window's end describe empty steps) */
+    auto step_at = [&](uint32_t ve0, uint32_t vleft, uint32_t vh0, uint32_t vmisc, int l) -> VoteStep {
+        VoteStep d;
+        const uint32_t misc = readlane_u(vmisc, l);
+        d.e0 = readlane_u(ve0, l);
+        d.left = readlane_u(vleft, l);
+        d.h0 = readlane_u(vh0, l);
+        d.R = (misc & 63u) + 1u;
+        d.i0 = (misc >> 6) & 127u;
+        d.i1 = (misc >> 13) & 127u;
+        d.valid = true;
+        return d;
+    };
     /* votes the units u0, u0 + stride, ... < total of the current set */
     auto vote_set = [&](uint32_t u0, uint32_t stride) {
         uint32_t incl = I_nu;
@@ -1008,16 +1021,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                 VoteStep ds[VOTE_GROUP];
 #pragma unroll
                 for (int g = 0; g < VOTE_GROUP; g++) {
-                    const int l = (int)((g0 + g) & (WAVE - 1));           /* past 63 only in the last group: any lane past n_w */
-                    const bool in = g0 + g < n_w;
-                    const uint32_t misc = in ? readlane_u(w_misc, l) : 0u;
-                    ds[g].e0 = in ? readlane_u(w_e0, l) : 0u;
-                    ds[g].left = in ? readlane_u(w_left, l) : 0u;
-                    ds[g].h0 = in ? readlane_u(w_h0, l) : 0u;
-                    ds[g].R = (misc & 63u) + 1u;
-                    ds[g].i0 = (misc >> 6) & 127u;
-                    ds[g].i1 = (misc >> 13) & 127u;
-                    ds[g].valid = true;
+                    ds[g] = step_at(w_e0, w_left, w_h0, w_misc, (int)g0 + g);
                     regs[g].load(e4, hits, ds[g], lane);
                 }
                 asm volatile("" ::: "memory");      /* all the group's loads are issued here, in this order: none sinks into its vote */
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 
     /* ---- peak extraction: local max, non-empty cells, emission ---- */
     uint32_t lmax = 0, nz = 0;
-    for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) {
+    for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
         const uint32_t v = acc[c];
         lmax = v > lmax ? v : lmax;
         nz += (v != 0);
@@ -1187,7 +1191,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 
     if (a.acc_dump && ref_ord == a.dump_ref) {
         uint32_t *dst = a.acc_dump + (size_t)m_base * OSLAMK_NBIN;
-        for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) dst[c] = acc[c];
+        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) dst[c] = acc[c];
     }
 
     /* cells with count > thresh * g (model.cu:164-167; g <= final maximum, so
@@ -1195,7 +1199,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const float bound = a.thresh * (float)s_g;
     if ((float)s_lmax > bound) {                 /* workgroup-uniform */
         uint32_t cnt = 0;
-        for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) cnt += ((float)acc[c] > bound);
+        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) cnt += ((float)acc[c] > bound);
         /* exclusive scan of cnt over the workgroup */
         uint32_t incl = cnt;
         for (int o = 1; o < WAVE; o <<= 1) {
@@ -1215,7 +1219,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         }
         __syncthreads();
         uint32_t pos = s_base + s_wave[wid] + incl - cnt;
-        for (int c = tid; c < ACC_CELLS; c += VOTE_THREADS) {
+        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
             const uint32_t v = acc[c];
             if ((float)v > bound) {
                 if (pos < a.out_cap) {

@@ -178,27 +178,38 @@ PM_HD uint32_t pc_vote_base_t24(uint32_t theta_v_t22)
     return ((theta_v_t22 + PC_T22_TURN / 2u) << 2) + PC_T24_MARGIN;
 }
 
-/* low 24 bits of a, times b (< 2^24): the two halves of v_mul_u32_u24 / v_mul_hi_u32_u24 */
-PM_HD uint32_t pc_mul24_lo(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xffffffu) * b); }
-PM_HD uint32_t pc_mul24_hi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xffffffu) * b) >> 32); }
+/* A model pair entry as the vote kernel streams it: theta_u << 10 | row, row = the model reference
+ * point's accumulator row inside its table slice (0..1022; 1023 = the sink row of padding entries).
+ * A vote is tm32 = pc_vote_base_t32(theta_v) - word: the angle difference sits in the upper 24 bits
+ * (units of 2^-24 turn << 8), and the row bits ride along below them -- they lower the difference by
+ * at most 1023/256 = 4 units of 2^-24 turn, which the base centres (+ 512 = 2 units) and the margin of
+ * 64 units absorbs: a vote is re-evaluated whenever it lies within 62 units of a bin edge, still 5.5 x
+ * the error bound.  Saves the shift of every entry and the select of its row in every step. */
+#define PC_ROW_BITS 10
+#define PC_ROW_MASK 0x3ffu
+#define PC_ROW_SINK 1023u
+PM_HD uint32_t pc_entry_word(uint32_t theta_u_t22, uint32_t row) { return (theta_u_t22 << PC_ROW_BITS) | row; }
+PM_HD uint32_t pc_vote_base_t32(uint32_t theta_v_t22) { return (pc_vote_base_t24(theta_v_t22) << 8) + 512u; }
 
 /* the reference's bin from the stored quantities (host-side statement of what the
- * vote kernel does; used by the CPU check of the scheme).  *needs_exact (optional) reports
- * whether the vote had to be re-evaluated, *pos_bins the unshifted quantised position. */
-PM_HD unsigned pc_alpha_bin_hybrid_ex(float uy, float uz, float vy, float vz, const uint32_t *tbl,
+ * vote kernel does; used by the CPU check of the scheme) for an entry in accumulator row `row`.
+ * *needs_exact (optional) reports whether the vote had to be re-evaluated, *pos_bins the
+ * unshifted quantised position. */
+PM_HD unsigned pc_alpha_bin_hybrid_ex(float uy, float uz, float vy, float vz, uint32_t row, const uint32_t *tbl,
                                       int *needs_exact, double *pos_bins)
 {
     const uint32_t cs = pc_angle_t22(vy, vz), am = pc_angle_t22(uy, uz);
-    const uint32_t tm = pc_vote_base_t24(cs) - (am << 2);
-    const int slow = cs == PC_T22_FORCE || am == PC_T22_FORCE || pc_mul24_lo(tm, PC_T24_SCALE) < PC_T24_EDGE;
+    const uint32_t tm32 = pc_vote_base_t32(cs) - pc_entry_word(am, row);
+    const uint64_t prod = (uint64_t)tm32 * 30u;           /* bin * 2^32 + position inside the (shifted) bin */
+    const int slow = cs == PC_T22_FORCE || am == PC_T22_FORCE || (uint32_t)prod < PC_T24_EDGE;
     if (needs_exact) *needs_exact = slow;
-    if (pos_bins) *pos_bins = (double)((tm - PC_T24_MARGIN) & 0xffffffu) * 30.0 / 16777216.0;
+    if (pos_bins) *pos_bins = (double)((((cs + PC_T22_TURN / 2u) << 2) - (am << 2)) & 0xffffffu) * 30.0 / 16777216.0;
     if (slow) return pc_alpha_bin_table(uy, uz, vy, vz, tbl);
-    return pc_mul24_hi(tm, PC_T24_SCALE);
+    return (unsigned)(prod >> 32);
 }
-PM_HD unsigned pc_alpha_bin_hybrid(float uy, float uz, float vy, float vz, const uint32_t *tbl)
+PM_HD unsigned pc_alpha_bin_hybrid(float uy, float uz, float vy, float vz, uint32_t row, const uint32_t *tbl)
 {
-    return pc_alpha_bin_hybrid_ex(uy, uz, vy, vz, tbl, 0, 0);
+    return pc_alpha_bin_hybrid_ex(uy, uz, vy, vz, row, tbl, 0, 0);
 }
 
 #endif /* OSLAM_PPF_CORE_H */

@@ -155,8 +155,10 @@ int main(int argc, char **argv)
                     vy = (float)(uy * c - uz * sn); vz = (float)(uy * sn + uz * c);
                 }
             }
-            unsigned a = hybrid ? pc_alpha_bin_hybrid(uy, uz, vy, vz, &PC_ALPHA_THR[0][0])
+            /* the row bits of the entry word ride along in the subtraction: both ends of their range must agree */
+            unsigned a = hybrid ? pc_alpha_bin_hybrid(uy, uz, vy, vz, (i & 8) ? PC_ROW_MASK : 0u, &PC_ALPHA_THR[0][0])
                                 : pc_alpha_bin_table(uy, uz, vy, vz, &PC_ALPHA_THR[0][0]);
+            if (hybrid && a != pc_alpha_bin_hybrid(uy, uz, vy, vz, (uint32_t)(r2 >> 20) & PC_ROW_MASK, &PC_ALPHA_THR[0][0])) a = 254u;
             /* the reference's own sequence with libm (kernel.cu:338-342) */
             float cx = uy * vz - uz * vy, dt = 0.0f * 0.0f + uy * vy + uz * vz;
             float al = atan2f(cx, dt) + PM_PI_F;
@@ -168,7 +170,7 @@ int main(int argc, char **argv)
                  * reference's alpha + pi: the quantity the margin has to cover */
                 int ne = 0;
                 double pos = 0.0;
-                (void)pc_alpha_bin_hybrid_ex(uy, uz, vy, vz, &PC_ALPHA_THR[0][0], &ne, &pos);
+                (void)pc_alpha_bin_hybrid_ex(uy, uz, vy, vz, 0u, &PC_ALPHA_THR[0][0], &ne, &pos);
                 double d = fabs(pos - (double)al / (double)PM_D_ANGLE);
                 if (d > 15.0) d = fabs(d - 30.0);
                 if (d > worst) worst = d;
