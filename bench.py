@@ -5,21 +5,27 @@ Metric (BASELINE.json): scene PPF votes/sec, 5k-point model vs 100k-point scene.
 A "step" is one pass of the hot path (Model::ppf_lookup: scene pair keys -> table
 probe -> votes -> peak extraction -> pose) of ONE resident model table against ONE
 scene already resident in HBM.  value = scene PPFs (valid ordered pairs
-(reference point r, i != r), each keyed, probed and fully voted) processed by all
-ranks per second.
+(reference point r, i != r)) processed by all ranks per second.  Every pair is taken
+through the path: its distance bin is tested against the model (exact: a pair in a bin
+that holds no model key cannot match, FNV collisions included), the pairs that pass
+(`pairs_probed`) are keyed and probed, the ones whose key is in the model (`hits`)
+vote with their whole bucket.  `hits_per_sec` and `vote_increments_per_sec` are the
+rates that do not depend on how much of the scene lies out of the model's reach.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: one process per GPU; scene reference points are dealt round-robin to
-ranks (no data-path collective); per step an RCCL all-reduce(MAX) of the local
-vote maximum and an all-gather of the records above the global threshold, then the host stage.
+ranks (no data-path collective); per step one oslam_align_multi call per rank (C-ABI):
+votes of the shard, RCCL all-reduce(MAX) of the vote maximum, all-gather of the records
+above the global threshold (device buffers end to end), pose tail on the union.
 Weak scaling: ref_point_df = 8 / N keeps 12.5k reference points per GPU.
 
 One JSON line on stdout (rank 0); progress goes to stderr.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -33,10 +39,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+KERNEL_SRC = os.path.join(ROOT, "objective-slam_amd", "csrc", "oslam_kernels.hip")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_source_hash():
+    with open(KERNEL_SRC, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def main():
@@ -64,8 +76,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    # OSLAM_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks
-    # (ranks share devices, the exchange runs on CPU tensors); the driver's runs use nccl = RCCL.
+    # OSLAM_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share
+    # devices, the exchange runs through host buffers); the driver's runs use nccl = RCCL, inside the C library.
     backend = os.environ.get("OSLAM_BENCH_BACKEND", "nccl")
     xdev = "cuda" if backend == "nccl" else "cpu"
     dev_index = local_rank % torch.cuda.device_count()
@@ -97,17 +109,20 @@ def main():
     model = ppf.Model(mp, mn, d_dist=d_dist, params=par)       # table resident in HBM
     t_build = time.time() - t0
     scene = ppf.Scene(sp, sn, d_dist=d_dist, ref_point_downsample_factor=df, params=par)   # resident in HBM
-    model.prepare(scene)      # device scratch pool and pose-tail tables: set-up, like the model table itself
+    model.prepare(scene)      # per-device counters and pose-tail tables: set-up, like the model table itself
+    comm = pkg.dist.make_comm(dev_index) if (world > 1 and backend == "nccl") else None
     log("[rank %d] model build %.3fs, d_dist %.5f, df %d" % (rank, t_build, d_dist, df))
 
-    def step():
+    def step(sc=scene):
         if world == 1:
-            T = model.ppf_lookup(scene)
+            T = model.ppf_lookup(sc)
             return T, dict(model.stats)
-        cells, lmax = model.align_local(scene, cap=pkg.dist.LOCAL_CAP)      # vote kernels on this shard
+        if comm is not None:
+            T = model.align_multi(sc, comm)                                    # one C call: votes + RCCL exchange + pose tail
+            return T, dict(model.stats)
+        allrec, gmax = pkg.dist.align_sharded_host(model, sc, xdev)            # rehearsal: same steps through host buffers
         st = dict(model.stats)
-        allrec, gmax = pkg.dist.gather_peaks(cells, lmax, xdev)             # RCCL all-reduce + all-gather
-        T = model.align_finish(scene, allrec, gmax)                          # pose tail on the union
+        T = model.align_finish(sc, allrec, gmax)
         st["num_top"] = model.stats["num_top"]
         return T, st
 
@@ -131,30 +146,59 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-    ppfs = torch.tensor([float(sum(s["num_scene_ppfs"] for s in stats_acc)),
-                         float(sum(s["num_votes"] for s in stats_acc))], dtype=torch.float64, device=xdev)
+    tot = torch.tensor([float(sum(s["num_scene_ppfs"] for s in stats_acc)),
+                        float(sum(s["num_votes"] for s in stats_acc)),
+                        float(sum(s["num_hits"] for s in stats_acc))], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ppfs, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
-    total_ppfs, total_votes = float(ppfs[0].item()), float(ppfs[1].item())
+    total_ppfs, total_votes, total_hits = (float(x) for x in tot.tolist())
+
+    # "H2D of the scene included and also reported separately": the same step with the Scene
+    # built from host buffers inside it (upload + reference frames on the host), a few repetitions, rank-local
+    t_incl = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sc2 = ppf.Scene(sp, sn, d_dist=d_dist, ref_point_downsample_factor=df, params=par)
+        t2 = time.perf_counter()
+        step(sc2)
+        torch.cuda.synchronize()
+        t_incl.append((time.perf_counter() - t1, t2 - t1))
+        sc2.close()
+    ms_incl = 1e3 * float(np.median([a for a, _ in t_incl]))
+    ms_scene = 1e3 * float(np.median([b for _, b in t_incl]))
 
     if rank == 0:
         st = stats_acc[-1]
-        n_slices = (M + 1023) // 1024
+        n_slices = (M + 1022) // 1023
         launches = sum(s["vote_launches"] for s in stats_acc)
         ms_vote_kernel = float(sum(s["ms_vote_kernel"] for s in stats_acc))   # HIP events around each launch
         ms_key_kernel = float(sum(s["ms_key_kernel"] for s in stats_acc))
         ms_path = float(np.mean([s["ms_vote"] for s in stats_acc]))
-        # Algorithmic bytes: 8 B per table probe, 8 B per vote (one model-pair
-        # entry), 16 B per emitted peak record; the vote kernel probes each hit once per slice.
-        vote_bytes_step = 8.0 * st["num_votes"] + 8.0 * st["num_hits"] * n_slices + 16.0 * st["num_emitted"]
-        per_launch_bytes = vote_bytes_step * args.steps / launches
         per_launch_ms = ms_vote_kernel / launches
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-        # whole path of one align: scene read once + probe per scene pair + votes + records
-        path_bytes = 24.0 * S + 8.0 * st["num_scene_ppfs"] + 8.0 * st["num_votes"] + 16.0 * st["num_emitted"]
+        steps_per_launch = args.steps / launches
+        # ---- k_vote, bytes this design cannot avoid: every bucket a run of hits needs is read once
+        # (4 B per model pair entry), 8 B of run record + 8 B of bucket record per (run, slice), 8 B per hit and
+        # slice for its angle, 16 B per emitted peak record
+        design_bytes_step = (4.0 * st["num_entries_streamed"] + 16.0 * st["num_items"] + 8.0 * st["num_hits"] * n_slices
+                             + 16.0 * st["num_emitted"])
+        design_launch = design_bytes_step * steps_per_launch
+        achieved = design_launch / (per_launch_ms * 1e-3) / 1e9
+        # ---- the same launch by SURVEY 8d's formula (8 B per vote, 8 B per probe, 16 B per record): not a
+        # ceiling for this design (an entry is 4 B and a bucket is read once per run of hits, not once per hit)
+        survey_bytes_step = 8.0 * st["num_votes"] + 8.0 * st["num_hits"] * n_slices + 16.0 * st["num_emitted"]
+        survey_launch = survey_bytes_step * steps_per_launch
+        survey_achieved = survey_launch / (per_launch_ms * 1e-3) / 1e9
+        path_bytes = 24.0 * S + 8.0 * st["num_pairs_probed"] + 8.0 * st["num_votes"] + 16.0 * st["num_emitted"]
+        votes_per_s_kernel = st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3)
+        # measured ceilings of the vote loop (tools/micro/): one conflict-free ds_add_u32 wave-instruction
+        # (64 votes) per 4.4 cycles per CU; 19 vector instructions = 70 SIMD cycles per 256 votes; 256 CUs, 2.4 GHz
+        lds_peak = 256 * 64 * 2.4e9 / 4.4
+        valu_peak = 1024 * 256 * 2.4e9 / 70.0
         dt, dr = ppf.ht_dist(T, poses[0][1])
+        traffic, traffic_note = pmc_traffic(args, M, S, df)
         out = {
             "metric": "scene_ppf_votes_per_sec",
             "value": total_ppfs / elapsed,
@@ -175,66 +219,79 @@ def main():
                        "vote_mode": args.vote_mode, "vote_count_threshold": 0.4,
                        "parallelism": "scene-ref-shard x%d" % world},
             "vote_increments_per_sec": total_votes / elapsed,
-            "per_step": {"scene_ppfs": st["num_scene_ppfs"], "hits": st["num_hits"], "votes": st["num_votes"],
+            "hits_per_sec": total_hits / elapsed,
+            "ms_per_step_incl_scene": ms_incl,
+            "ms_scene_create": ms_scene,
+            "per_step": {"scene_ppfs": st["num_scene_ppfs"], "pairs_probed": st["num_pairs_probed"],
+                         "hits": st["num_hits"], "votes": st["num_votes"],
+                         "entries_streamed": st["num_entries_streamed"], "buckets_streamed": st["num_items"],
                          "nonempty_cells": st["num_unique_votes"], "model_keys": st["num_model_keys"],
                          "max_cell": st["max_count"], "emitted_records": st["num_emitted"],
-                         "top_cells": st.get("num_top", 0)},
+                         "top_cells": st.get("num_top", 0), "hit_list_pool_bytes": st["scratch_bytes"]},
             "pose": {"rot_err_deg": float(np.degrees(dr)), "trans_err_frac_diam": dt / diam,
                      "ok_at_reference_criterion_12deg_0.1diam": bool(dr < np.radians(12) and dt < 0.1 * diam)},
             "model_build_s": t_build,
             "roofline": {"bound": "hbm", "kernel": "k_vote", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic(args, M, S, df),
-                         "traffic_note": "HBM-side bytes per vote-kernel launch (rocprofv3 PMC, profiles/). Far below the "
-                                         "algorithmic bytes, and frac above 1, because the SURVEY 8d model charges 8 B to "
-                                         "every vote while the kernel packs an entry into 4 B and streams a bucket once "
-                                         "for all hits of a reference point that share it; the kernel is bound by "
-                                         "LDS-atomic and vector issue, not by HBM (DESIGN.md 4)",
-                         "alg_bytes_per_launch": per_launch_bytes, "launch_ms": per_launch_ms,
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "alg_bytes_per_launch": design_launch, "launch_ms": per_launch_ms,
                          "launches_per_step": launches / args.steps,
-                         "key_kernel_ms_per_step": ms_key_kernel / args.steps,
-                         "path_achieved_GBps": path_bytes / (ms_path * 1e-3) / 1e9,
-                         "path_alg_bytes_per_step": path_bytes, "path_kernels_ms_per_step": ms_path,
+                         "alg_bytes_model": "4 B x model pair entries streamed (each bucket once per run of hits and slice) "
+                                            "+ 16 B per (run, slice) + 8 B per hit and slice + 16 B per record",
+                         "binding": "vector issue, then LDS atomics: see roofline_valu / roofline_lds_atomic "
+                                    "(DESIGN.md 4); the entry stream comes out of the Infinity Cache",
+                         "key_kernels_ms_per_step": ms_key_kernel / args.steps,
+                         "path_kernels_ms_per_step": ms_path,
                          "torch_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps},
+            "roofline_valu": {"bound": "valu_issue", "kernel": "k_vote", "unit": "votes/s", "achieved": votes_per_s_kernel,
+                              "peak": valu_peak, "frac": votes_per_s_kernel / valu_peak,
+                              "note": "votes per second of vote-kernel time against 256 votes per 70 SIMD cycles "
+                                      "(the 19 vector instructions of one exact vote iteration, measured rates)"},
+            "roofline_lds_atomic": {"bound": "lds_atomic", "kernel": "k_vote", "unit": "votes/s",
+                                    "achieved": votes_per_s_kernel, "peak": lds_peak, "frac": votes_per_s_kernel / lds_peak,
+                                    "note": "against the measured conflict-free ds_add_u32 rate of the chip"},
+            "roofline_survey_8d": {"bound": "hbm", "kernel": "k_vote", "achieved": survey_achieved, "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": survey_achieved / HBM_PEAK_GBPS,
+                                   "alg_bytes_per_launch": survey_launch,
+                                   "path_achieved_GBps": path_bytes / (ms_path * 1e-3) / 1e9,
+                                   "note": "SURVEY.md 8d's byte model (8 B per vote): above 1 by construction for a design that "
+                                           "packs an entry into 4 B and streams a bucket once per run of hits; kept for comparison"},
         }
-        # What binds the vote kernel in fact: the LDS atomics, one per vote.  Peak from
-        # tools/micro/lds_atomic_bench.hip on MI355X: one conflict-free ds_add_u32 wave-instruction
-        # (64 lane-atomics) per 4.4 cycles per CU, 256 CUs, 2.4 GHz.
-        lds_peak = 256 * 64 * 2.4e9 / 4.4
-        out["roofline_lds_atomic"] = {"bound": "lds_atomic", "kernel": "k_vote", "unit": "votes/s",
-                                      "achieved": st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3),
-                                      "peak": lds_peak,
-                                      "frac": st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3) / lds_peak,
-                                      "note": "secondary, informational: votes per second of vote-kernel time against the "
-                                              "measured conflict-free LDS-atomic rate of the chip"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mp, mn, sp, sn, df, d_dist)
             out["pose_recall_at_1deg"] = pose_recall(ppf, synth, mode)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def pmc_traffic(args, M, S, df):
-    """HBM bytes per vote-kernel launch from the committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_traffic.json of the latest round; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as
-    read), or None when no pass for this workload is on file.  Counters cannot be read from
-    inside the timed process, so this is the one roofline field that is not measured live."""
+    """HBM-side bytes per vote-kernel launch from the rocprofv3 PMC passes of the latest round
+    (profiles/rNN_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read).
+    Counters cannot be read from inside the timed process, so this is the one roofline field that is
+    not measured live; it is reported only when the passes were taken with the kernel source that is
+    running now (hash on file) and for this workload -- otherwise null, with the reason."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
     if not files:
-        return None
+        return None, "no PMC passes on file"
     try:
         with open(files[-1]) as f:          # the latest round's passes
             rec = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "unreadable " + os.path.basename(files[-1])
+    if rec.get("kernel_source_sha16") != kernel_source_hash():
+        return None, ("%s was taken with another oslam_kernels.hip (stale): re-run tools/profile_round.sh"
+                      % os.path.basename(files[-1]))
     for r in rec.get("runs", []):
         if (r["model_points"], r["scene_points"], r["ref_point_df"], r["vote_mode"], r["tau_d"]) == \
                 (M, S, df, args.vote_mode, args.tau_d):
-            return r["hbm_bytes_per_vote_launch"]
-    return None
+            return r["hbm_bytes_per_vote_launch"], ("HBM-side bytes per vote-kernel launch, rocprofv3 PMC passes of %s "
+                                                    "(same kernel source)" % os.path.basename(files[-1]))
+    return None, "no PMC pass for this workload in " + os.path.basename(files[-1])
 
 
 def pose_recall(ppf, synth, mode, trials=6):

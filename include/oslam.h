@@ -77,6 +77,8 @@ typedef struct oslam_stats {
     uint64_t num_pairs_probed;     /* of num_scene_ppfs, the pairs whose distance bin can reach a model key: they are keyed
                                     * and probed; the others cannot hit and are dropped by the distance test alone */
     uint64_t scratch_bytes;        /* size of the device's hit-list pool after this call */
+    uint64_t num_entries_streamed; /* model pair entries the vote kernel read: bucket lengths summed over (run of hits, table slice) */
+    uint64_t num_items;            /* (run of hits, table slice) pairs with a bucket = buckets streamed */
 } oslam_stats;
 
 /* One accumulator peak: code = s_r << 32 | m_r << 6 | alpha_idx (kernel.cu:549). */

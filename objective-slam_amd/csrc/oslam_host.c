@@ -1215,6 +1215,8 @@ static int vote_and_fetch(scratch_pool *pool, oslam_model *m, oslam_scene *s, os
         st->ms_key_kernel = msk;
         st->vote_launches = launches;
         st->num_pairs_probed = probed;
+        st->num_entries_streamed = cnt->entries;
+        st->num_items = cnt->items;
         st->scratch_bytes = pool->bytes;
     }
 done:

@@ -81,6 +81,8 @@ typedef struct oslamk_counters {
     uint32_t gmax;
     uint32_t out_count;
     uint32_t pad[2];
+    unsigned long long entries;   /* model pair entries streamed: sum of the bucket lengths over (run, slice) */
+    unsigned long long items;     /* (run, slice) pairs with a bucket */
     unsigned long long prof[4];   /* -DVOTE_PROF builds: k_vote wave cycles (end of voting, barrier, peak extraction, vote steps) */
 } oslamk_counters;
 

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     for (int c = tid; c < ACC_CELLS / 4; c += VOTE_THREADS) reinterpret_cast<uint4 *>(acc)[c] = make_uint4(0, 0, 0, 0);
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
 
-    unsigned long long my_votes = 0;
+    unsigned long long my_votes = 0, my_entries = 0;
     unsigned long long *sq = s_slow + (MODE == 0 ? wid * SLOW_CAP : 0);   /* this wave's re-evaluation queue */
     uint32_t sq_n = 0;
 #ifdef VOTE_PROF
@@ -942,7 +942,10 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
                 const oslamk_run rr = runs[k];
                 const uint32_t lf = uinfo[rr.slot_r & RUN_SLOT_MASK].len;
                 const uint32_t ln = lf & 0x7fffffffu, R = (rr.slot_r >> OSLAMK_RUN_SHIFT) + 1u;
-                if (first) my_votes += (unsigned long long)ln * R;
+                if (first) {
+                    my_votes += (unsigned long long)ln * R;
+                    my_entries += ((unsigned long long)(ln != 0u) << 40) + ln;       /* items in the upper bits: one reduction for both */
+                }
                 /* items with a marker (MODE 0) are neither giants nor small items: they wait for the pass after the loop */
                 giant = ((ln + 255u) >> 8) * R > T && !(MODE == 0 && ((lf | rr.first) >> 31));
             }
@@ -1161,10 +1164,15 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     lmax = wave_max_u32(lmax);
     nz = wave_sum_u32(nz);
     my_votes = wave_sum_u64(my_votes);
+    my_entries = wave_sum_u64(my_entries);
     if (lane == 0) {
         s_wave[wid] = lmax;
         s_wave2[wid] = nz;
         s_wave64[wid] = my_votes;
+        if (my_entries) {
+            atomicAdd(&a.counters->entries, my_entries & 0xffffffffffull);
+            atomicAdd(&a.counters->items, my_entries >> 40);
+        }
     }
     __syncthreads();
     if (tid == 0) {

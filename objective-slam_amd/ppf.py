@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("max_count", C.c_uint32), ("num_emitted", C.c_uint32), ("ms_vote", C.c_float),
                 ("ms_total", C.c_float), ("vote_launches", C.c_uint32), ("ms_vote_kernel", C.c_float),
                 ("ms_key_kernel", C.c_float), ("reserved0", C.c_uint32), ("num_pairs_probed", C.c_uint64),
-                ("scratch_bytes", C.c_uint64)]
+                ("scratch_bytes", C.c_uint64), ("num_entries_streamed", C.c_uint64), ("num_items", C.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved0"}

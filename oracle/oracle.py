@@ -76,6 +76,8 @@ def lib():
     L.orc_voxel_grid.argtypes = [vp, vp, C.c_size_t, C.c_float, vp, vp]
     L.orc_depth_to_cloud.restype = C.c_long
     L.orc_depth_to_cloud.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [C.c_float] * 8 + [vp, vp]
+    L.orc_pose_from_cells_w.restype = C.c_int
+    L.orc_pose_from_cells_w.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.orc_pose_from_cells.restype = C.c_int
     L.orc_pose_from_cells.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int,
                                       C.c_int, vp]
@@ -218,12 +220,15 @@ def trans_calc2(cells, mp, mn, sp, sn):
 
 
 def pose_from_cells(cells, mp, mn, sp, sn, d_dist, cpu_clustering=False, use_l1_norm=False,
-                    use_averaged_clusters=False):
+                    use_averaged_clusters=False, weights=None):
+    """weights: Model::SetModelPointVoteWeights (model.cu:84-93); None = all 1 (model.cu:67)."""
     mp, mn, sp, sn = _c32(mp), _c32(mn), _c32(sp), _c32(sn)
     cells = np.ascontiguousarray(cells, CELL_DTYPE)
     T = np.zeros(16, np.float32)
-    rc = lib().orc_pose_from_cells(_p(cells), len(cells), _p(mp), _p(mn), _p(sp), _p(sn), float(d_dist),
-                                   int(cpu_clustering), int(use_l1_norm), int(use_averaged_clusters), _p(T))
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    rc = lib().orc_pose_from_cells_w(_p(cells), len(cells), _p(mp), _p(mn), _p(sp), _p(sn), float(d_dist),
+                                     int(cpu_clustering), int(use_l1_norm), int(use_averaged_clusters),
+                                     _p(w) if w is not None else None, _p(T))
     return rc, T.reshape(4, 4)
 
 

@@ -634,14 +634,20 @@ void orc_trans2idx(const orc_f3 *trans, size_t n, float d_dist, uint32_t *trans_
     }
 }
 
-/* model.cu:173-189 (K6, weights all 1.0: model.cu:67), :202-244 (K7 done by
- * caller, K8, table, lower_bound, K9 kernel.cu:702-763), :292-295 (argmax) */
-size_t orc_cluster_gpu_style(const orc_cell *cells, size_t n, orc_f3 *trans, const orc_f4 *quat,
-                             float d_dist, int use_l1_norm, int use_averaged_clusters,
-                             float *scores_out)
+/* model.cu:173-189 (K6 = vote_weight_kernel, kernel.cu:766-782: weight of the cell's model point times
+ * its count; the weights are all 1.0 unless SetModelPointVoteWeights was called, model.cu:67,84-93),
+ * :202-244 (K7 done by caller, K8, table, lower_bound, K9 kernel.cu:702-763), :292-295 (argmax).
+ * model_point_weights == NULL: all 1.0. */
+size_t orc_cluster_gpu_style_w(const orc_cell *cells, size_t n, orc_f3 *trans, const orc_f4 *quat,
+                               float d_dist, int use_l1_norm, int use_averaged_clusters,
+                               const float *model_point_weights, float *scores_out)
 {
     float *weighted = (float *)malloc(sizeof(float) * (n ? n : 1));
-    if (n > 1) for (size_t i = 0; i < n; i++) weighted[i] = 1.0f * cells[i].count;  /* K6 */
+    if (n > 1)
+        for (size_t i = 0; i < n; i++) {                                           /* K6 */
+            uint32_t model_point_idx = ((uint32_t)cells[i].code) >> 6;            /* kernel.cu:774-775 */
+            weighted[i] = (model_point_weights ? model_point_weights[model_point_idx] : 1.0f) * cells[i].count;
+        }
     else memset(weighted, 0, sizeof(float) * n);                                   /* kernel.cu:769 */
     uint32_t *th = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
     uint32_t *adj = (uint32_t *)malloc(sizeof(uint32_t) * 27 * (n ? n : 1));
@@ -692,6 +698,13 @@ size_t orc_cluster_gpu_style(const orc_cell *cells, size_t n, orc_f3 *trans, con
     orc_table_free(&tab);
     free(weighted); free(th); free(adj);
     return best;
+}
+
+size_t orc_cluster_gpu_style(const orc_cell *cells, size_t n, orc_f3 *trans, const orc_f4 *quat,
+                             float d_dist, int use_l1_norm, int use_averaged_clusters,
+                             float *scores_out)
+{
+    return orc_cluster_gpu_style_w(cells, n, trans, quat, d_dist, use_l1_norm, use_averaged_clusters, 0, scores_out);
 }
 
 /* ---------------------------------------------------------------------------
@@ -812,9 +825,10 @@ int orc_cluster_poses_cpu(const float *T, const orc_cell *cells, size_t n, float
 }
 
 /* model.cu:269-306 + ppf.cu:74-93 */
-int orc_pose_from_cells(const orc_cell *cells, size_t n, const orc_f3 *mp, const orc_f3 *mn,
-                        const orc_f3 *sp, const orc_f3 *sn, float d_dist, int cpu_clustering,
-                        int use_l1_norm, int use_averaged_clusters, float T_out[16])
+int orc_pose_from_cells_w(const orc_cell *cells, size_t n, const orc_f3 *mp, const orc_f3 *mn,
+                          const orc_f3 *sp, const orc_f3 *sn, float d_dist, int cpu_clustering,
+                          int use_l1_norm, int use_averaged_clusters, const float *model_point_weights,
+                          float T_out[16])
 {
     memset(T_out, 0, 16 * sizeof(float));
     if (n == 0) return 1;
@@ -829,12 +843,20 @@ int orc_pose_from_cells(const orc_cell *cells, size_t n, const orc_f3 *mp, const
         orc_f4 *qu = (orc_f4 *)malloc(sizeof(orc_f4) * n);
         float *sc = (float *)malloc(sizeof(float) * n);
         orc_mat2transquat(T, n, tr, qu);
-        size_t best = orc_cluster_gpu_style(cells, n, tr, qu, d_dist, use_l1_norm,
-                                            use_averaged_clusters, sc);
+        size_t best = orc_cluster_gpu_style_w(cells, n, tr, qu, d_dist, use_l1_norm,
+                                              use_averaged_clusters, model_point_weights, sc);
         memcpy(T_out, T + 16 * best, 16 * sizeof(float));
         T_out[3] = tr[best].x; T_out[7] = tr[best].y; T_out[11] = tr[best].z;  /* ppf.cu:90-92 */
         free(tr); free(qu); free(sc);
     }
     free(T);
     return 0;
+}
+
+int orc_pose_from_cells(const orc_cell *cells, size_t n, const orc_f3 *mp, const orc_f3 *mn,
+                        const orc_f3 *sp, const orc_f3 *sn, float d_dist, int cpu_clustering,
+                        int use_l1_norm, int use_averaged_clusters, float T_out[16])
+{
+    return orc_pose_from_cells_w(cells, n, mp, mn, sp, sn, d_dist, cpu_clustering, use_l1_norm,
+                                 use_averaged_clusters, 0, T_out);
 }

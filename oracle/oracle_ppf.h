@@ -136,6 +136,14 @@ void orc_ht_dist(const float A[16], const float B[16], float out[2]);
 int orc_pose_from_cells(const orc_cell *cells, size_t n, const orc_f3 *mp, const orc_f3 *mn,
                         const orc_f3 *sp, const orc_f3 *sn, float d_dist, int cpu_clustering,
                         int use_l1_norm, int use_averaged_clusters, float T_out[16]);
+/* the same with Model::SetModelPointVoteWeights (model.cu:84-93, kernel.cu:766-782); NULL = all 1 */
+int orc_pose_from_cells_w(const orc_cell *cells, size_t n, const orc_f3 *mp, const orc_f3 *mn,
+                          const orc_f3 *sp, const orc_f3 *sn, float d_dist, int cpu_clustering,
+                          int use_l1_norm, int use_averaged_clusters, const float *model_point_weights,
+                          float T_out[16]);
+size_t orc_cluster_gpu_style_w(const orc_cell *cells, size_t n, orc_f3 *trans, const orc_f4 *quat,
+                               float d_dist, int use_l1_norm, int use_averaged_clusters,
+                               const float *model_point_weights, float *scores_out);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,21 @@ def test_model_database_round_trip(ppf, oracle, built_lib, case_two_slices, tmp_
     with pytest.raises(ppf.OslamError) as e:
         ppf.Model.load(g)
     assert "truncated" in str(e.value)
+    # header fields a kernel indexes with (db_header: magic u64, version, vote_mode, n_points, n_slices, cap,
+    # shift, ucap, ushift, n_entries, has_uv): a stale shift, a bucket table that is not a power of two, an exact
+    # table without its exact entries and a flipped bit in an unchecked-looking field are all refused before
+    # anything reaches the GPU (the checksum covers the header as well)
+    good = bytearray(open(f, "rb").read())
+    for off, val, what in ((28, 7, "inconsistent"), (24, 3000, "inconsistent"), (44, 0, "inconsistent"), (48, None, "checksum")):
+        bad = bytearray(good)
+        if val is None:
+            bad[off] ^= 1                      # num_model_keys: consistent with everything, but not what was written
+        else:
+            bad[off:off + 4] = int(val).to_bytes(4, "little")
+        open(g, "wb").write(bytes(bad))
+        with pytest.raises(ppf.OslamError) as e:
+            ppf.Model.load(g)
+        assert what in str(e.value), (off, str(e.value))
 
 
 def _align_and_compare(ppf, oracle, c, df=1, **flags):
@@ -574,8 +589,10 @@ def test_device_pose_tail_equals_oracle(ppf, oracle, built_lib, case_small, case
     w = np.linspace(0.1, 3.0, len(c["mp"])).astype(np.float32)
     mo.SetModelPointVoteWeights(w)
     Tw = mo.ppf_lookup(sc)
-    Th, _ = ppf.pose_stage(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], weights=w)
-    assert np.array_equal(Tw, Th)
+    _, Tow = oracle.pose_from_cells(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], weights=w)   # kernel.cu:766-782
+    assert np.array_equal(Tw, Tow)
+    Th, _ = ppf.pose_stage(ocells, c["mp"], c["mn"], c["sp"], c["sn"], c["d"], weights=w)           # the host tail too
+    assert np.array_equal(Th, Tow)
     # sharded: three local peak lists -> union -> align_finish on the device
     all_cells, gmax = [], 0
     for rank in range(3):
