@@ -212,6 +212,22 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
                      int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
                      const float *model_point_weights, float T_rowmajor[16], float *poses_out);
 
+/* The other result fields of the reference's Model after ppf_lookup (include/model.h:100-113, read by
+ * src/cuda/ppf.cu:74-93) for the cells oslam_last_cells returns, recomputed on the host from those cells
+ * (the same arithmetic as the registration itself): trans_out [n][3] = transformation_trans (after the
+ * clustering stage, i.e. averaged when use_averaged_clusters), rots_out [n][4] = transformation_rots
+ * (w, x, y, z, kernel.cu:124-144), vote_counts_out [n] = the clustered scores, *max_idx_out = max_idx.
+ * With cpu_clustering the reference fills cpu_transformations instead: vote_counts_out[0] = votes of the
+ * winning cluster, its pose is the T of oslam_align.  s: the scene of that registration.  Any output may be
+ * NULL; at most cap cells are written, *n_out = their number. */
+int oslam_last_result(oslam_model *m, oslam_scene *s, float *trans_out, float *rots_out, float *vote_counts_out,
+                      size_t cap, size_t *n_out, uint32_t *max_idx_out);
+int oslam_pose_stage_ex(const oslam_cell *cells, size_t n, const float *m_xyz, const float *m_nrm,
+                        size_t M, const float *s_xyz, const float *s_nrm, size_t S, float d_dist,
+                        int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
+                        const float *model_point_weights, float T_rowmajor[16], float *poses_out,
+                        float *trans_out, float *rots_out, float *scores_out, uint32_t *max_idx_out);
+
 /* ---- multi-GPU: scene reference points shard across ranks (one process per GPU;
  * params.shard_rank / shard_world at oslam_scene_create), model tables replicated.  The reference
  * has no multi-GPU code (src/cuda/ppf.cu:45 picks one device); its one call does everything

@@ -24,8 +24,10 @@
 #define OSLAM_PCL_HPP
 
 #include <cstddef>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "oslam.h"
@@ -69,7 +71,7 @@ class Model {
   public:
     Model(CloudT *cloud, float d_dist, float vote_count_threshold, bool cpu_clustering, bool use_l1_norm,
           bool use_averaged_clusters, int dev = 0)
-        : cloud_ptr(cloud), h_(nullptr)
+        : cloud_ptr(cloud), h_(nullptr), cpu_clustering_(cpu_clustering)
     {
         oslam_params p;
         oslam_params_default(&p);
@@ -90,19 +92,62 @@ class Model {
     {
         check(oslam_model_set_point_weights(h_, w.data(), w.size()));
     }
-    /* best pose lands in best_T (row-major), counters in stats */
+    /* Model::ppf_lookup (model.cu:269-306).  Afterwards the result fields below hold what the reference's
+     * hold (model.h:92-113), for the cells above the threshold in (count descending, code ascending) order;
+     * best_T (row-major) is what ppf.cu:74-93 extracts from them; counters in stats. */
     template <class SceneT>
     void ppf_lookup(SceneT *scene)
     {
         check(oslam_align(h_, scene->handle(), best_T, &stats));
+        std::size_t n = 0;
+        check(oslam_last_cells(h_, nullptr, nullptr, 0, &n));
+        std::vector<oslam_cell> cells(n ? n : 1);
+        transformations.assign(16 * n, 0.0f);
+        transformation_trans.assign(n, float3_t{0, 0, 0});
+        transformation_rots.assign(n, float4_t{0, 0, 0, 0});
+        vote_counts_out.assign(n, 0.0f);
+        voteCodes.resize(n);
+        voteCounts.resize(n);
+        cpu_transformations.clear();
+        max_idx = 0;
+        if (n) {
+            check(oslam_last_cells(h_, cells.data(), transformations.data(), n, &n));
+            check(oslam_last_result(h_, scene->handle(), &transformation_trans[0].x, &transformation_rots[0].x,
+                                    vote_counts_out.data(), n, &n, &max_idx));
+            for (std::size_t i = 0; i < n; i++) {
+                voteCodes[i] = cells[i].code;
+                voteCounts[i] = cells[i].count;
+            }
+        }
+        if (cpu_clustering_) {                       /* ClusterTransformationsCPU: the winning cluster first (ppf.cu:75-77) */
+            PoseWithVotes pv;
+            for (int k = 0; k < 16; k++) pv.pose[k] = best_T[k];
+            pv.votes = n ? (unsigned int)vote_counts_out[0] : 0u;
+            cpu_transformations.push_back(pv);
+        }
     }
+    const std::vector<float> &getTransformations() const { return transformations; }
     oslam_model *handle() const { return h_; }
     CloudT *cloud_ptr;
+
+    /* ---- the reference's public result fields (model.h:92-113), on the host ---- */
+    struct float3_t { float x, y, z; };
+    struct float4_t { float x, y, z, w; };                 /* a quaternion as (w, x, y, z) in (.x, .y, .z, .w): kernel.cu:124-144 */
+    struct PoseWithVotes { float pose[16]; unsigned int votes; };   /* transformation_clustering.h */
+    std::vector<unsigned long long> voteCodes;             /* [scene ref | model point << 6 | angle], kernel.cu:549 */
+    std::vector<unsigned int> voteCounts;
+    std::vector<float> transformations;                    /* 4x4 row-major per cell, linear indexing as the reference's */
+    std::vector<float3_t> transformation_trans;            /* after the clustering stage (kernel.cu:758) */
+    std::vector<float4_t> transformation_rots;
+    std::vector<float> vote_counts_out;                    /* clustered scores (kernel.cu:702-763) */
+    std::vector<PoseWithVotes> cpu_transformations;        /* with cpu_clustering: [0] = the winning cluster's pose */
+    unsigned int max_idx = 0;
     float best_T[16] = {0};
     oslam_stats stats{};
 
   private:
     oslam_model *h_;
+    bool cpu_clustering_;
 };
 
 /* ppf_registration -- ppf.h:9-15.  CloudPtr is e.g. pcl::PointCloud<pcl::PointNormal>::Ptr;
@@ -120,10 +165,10 @@ std::vector<std::vector<Matrix4>> ppf_registration(std::vector<CloudPtr> scene_c
     (void)model_weights;
     using CloudT = typename std::remove_reference<decltype(*scene_clouds[0])>::type;
     std::vector<std::vector<Matrix4>> results;
-    std::vector<Model<CloudT> *> models;
+    std::vector<std::unique_ptr<Model<CloudT>>> models;      /* released also when a later step throws */
     for (std::size_t j = 0; j < model_clouds.size(); j++)
-        models.push_back(new Model<CloudT>(&*model_clouds[j], model_d_dists[j], vote_count_threshold,
-                                           cpu_clustering, use_l1_norm, use_averaged_clusters, devUse));
+        models.emplace_back(new Model<CloudT>(&*model_clouds[j], model_d_dists[j], vote_count_threshold,
+                                              cpu_clustering, use_l1_norm, use_averaged_clusters, devUse));
     oslam_params sp;
     oslam_params_default(&sp);
     sp.dev = devUse;
@@ -132,14 +177,27 @@ std::vector<std::vector<Matrix4>> ppf_registration(std::vector<CloudPtr> scene_c
         for (std::size_t j = 0; j < model_clouds.size(); j++) {
             /* the scene is prepared per model: its keys depend on the model's d_dist (ppf.cu:64-67) */
             Scene<CloudT> scene(&*scene_clouds[i], model_d_dists[j], ref_point_downsample_factor, &sp);
-            models[j]->ppf_lookup(&scene);
+            Model<CloudT> *model = models[j].get();
+            model->ppf_lookup(&scene);
             Matrix4 T;
-            for (int r = 0; r < 4; r++)
-                for (int c = 0; c < 4; c++) T(r, c) = models[j]->best_T[4 * r + c];
+            /* the extraction of ppf.cu:74-93, from the same fields */
+            if (cpu_clustering && !model->cpu_transformations.empty()) {
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) T(r, c) = model->cpu_transformations[0].pose[4 * r + c];
+            } else if (model->transformation_trans.size() >= 2) {
+                const std::vector<float> &transformations = model->getTransformations();
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) T(r, c) = transformations[model->max_idx * 16 + r * 4 + c];
+                T(0, 3) = model->transformation_trans[model->max_idx].x;
+                T(1, 3) = model->transformation_trans[model->max_idx].y;
+                T(2, 3) = model->transformation_trans[model->max_idx].z;
+            } else {                                 /* no cell, or a single one: the zero pose (kernel.cu:609) */
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) T(r, c) = model->best_T[4 * r + c];
+            }
             results.back().push_back(T);
         }
     }
-    for (auto *m : models) delete m;
     return results;
 }
 

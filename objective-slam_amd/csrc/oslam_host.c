@@ -1786,6 +1786,7 @@ done:
 int oslam_scene_keys(oslam_scene *s, size_t ref_index, uint32_t *keys_out)
 {
     if (!s) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (!(s->d_dist > 0.0f)) return fail(OSLAM_E_INVALID, "this scene was made for models of any d_dist (d_dist 0): it has no keys of its own");
     if (hipSetDevice(s->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
     return cloud_row_keys(&s->c, ref_index, s->d_dist, keys_out);
 }
@@ -1910,6 +1911,42 @@ done:
     if (d_dump) (void)hipFree(d_dump);
     if (d_ref) (void)hipFree(d_ref);
     if (d_tsg) (void)hipFree(d_tsg);
+    return rc;
+}
+
+int oslam_last_result(oslam_model *m, oslam_scene *s, float *trans_out, float *rots_out, float *vote_counts_out,
+                      size_t cap, size_t *n_out, uint32_t *max_idx_out)
+{
+    int rc;
+    size_t n;
+    float T[16], *tr = NULL, *ro = NULL, *sc = NULL;
+    uint32_t best = 0;
+    if (!n_out) return fail(OSLAM_E_INVALID, "NULL argument");
+    *n_out = 0;
+    rc = check_pair(m, s);
+    if (rc != OSLAM_OK) return rc;
+    if (materialise_last(m) != OSLAM_OK) return OSLAM_E_DEVICE;
+    n = m->n_last;
+    if (max_idx_out) *max_idx_out = 0;
+    if (n == 0) return OSLAM_OK;
+    tr = (float *)calloc(3 * n, sizeof(float));
+    ro = (float *)calloc(4 * n, sizeof(float));
+    sc = (float *)calloc(n, sizeof(float));
+    if (!tr || !ro || !sc) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    rc = oslam_pose_stage_ex(m->last_cells, n, m->c.h_xyz, m->c.h_nrm, (size_t)m->c.n, s->c.h_xyz, s->c.h_nrm, (size_t)s->c.n,
+                             m->d_dist, m->params.cpu_clustering, m->params.use_l1_norm, m->params.use_averaged_clusters,
+                             m->weights, T, NULL, tr, ro, sc, &best);
+    if (rc != OSLAM_OK) { rc = fail(rc, "pose stage failed"); goto done; }
+    if (n > cap) n = cap;
+    if (trans_out) memcpy(trans_out, tr, sizeof(float) * 3 * n);
+    if (rots_out) memcpy(rots_out, ro, sizeof(float) * 4 * n);
+    if (vote_counts_out) memcpy(vote_counts_out, sc, sizeof(float) * n);
+    if (max_idx_out) *max_idx_out = best;
+    *n_out = n;
+done:
+    free(tr);
+    free(ro);
+    free(sc);
     return rc;
 }
 

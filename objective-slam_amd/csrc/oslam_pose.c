@@ -233,8 +233,9 @@ static __thread oslam_cluster_hook g_cluster_hook;
 void oslam_pose_set_cluster_hook(oslam_cluster_hook hook) { g_cluster_hook = hook; }
 
 /* ---- K6 + K8 + K9 + argmax: returns max_idx ---- */
+#define NO_MEMORY ((size_t)-1)
 static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, const float *quat,
-                               float d_dist, int use_l1, int averaged, const float *weights)
+                               float d_dist, int use_l1, int averaged, const float *weights, float *score_out)
 {
     float *wv = (float *)malloc(sizeof(float) * n);
     float *score = (float *)calloc(n, sizeof(float));
@@ -242,6 +243,10 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
     hash_idx *hi = (hash_idx *)malloc(sizeof(hash_idx) * n);
     const float rot_thresh = 2 * POSE_D, rot_thresh_sq = rot_thresh * rot_thresh;
     size_t i, best = 0;
+    if (!wv || !score || !cell || !hi) {
+        free(wv); free(score); free(cell); free(hi);
+        return NO_MEMORY;
+    }
 
     for (i = 0; i < n; i++) {
         uint32_t m = ((uint32_t)cells[i].code) >> 6;
@@ -313,6 +318,7 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
         }
     }
     for (i = 1; i < n; i++) if (score[i] > score[best]) best = i;         /* model.cu:292-295 */
+    if (score_out) memcpy(score_out, score, sizeof(float) * n);           /* vote_counts_out, model.h:104 */
     free(wv); free(score); free(cell); free(hi);
     return best;
 }
@@ -369,8 +375,8 @@ int oslam_ht_dist(const float A[16], const float B[16], float out[2])
 
 /* greedy clustering, transformation_clustering.cpp:62-122; poses arrive sorted
  * by votes; the first cluster's average pose is the result (ppf.cu:75-77) */
-static void cluster_greedy(const float *T, const oslam_cell *cells, size_t n, float trans_thresh,
-                           float rot_thresh, float *T_out)
+static int cluster_greedy(const float *T, const oslam_cell *cells, size_t n, float trans_thresh,
+                          float rot_thresh, float *T_out, uint32_t *votes_out)
 {
     size_t *head = (size_t *)malloc(sizeof(size_t) * n);
     size_t *member = (size_t *)malloc(sizeof(size_t) * n);
@@ -378,6 +384,10 @@ static void cluster_greedy(const float *T, const oslam_cell *cells, size_t n, fl
     size_t ncl = 0, p, c, win = 0, cnt = 0;
     float ta[3] = {0, 0, 0}, qa[4] = {0, 0, 0, 0}, nq, x, y, z, w;
     int i, j;
+    if (!head || !member || !cvotes) {
+        free(head); free(member); free(cvotes);
+        return OSLAM_E_NOMEM;
+    }
     for (p = 0; p < n; p++) {
         const float *P = T + 16 * p;
         for (c = 0; c < ncl; c++) {
@@ -413,7 +423,9 @@ static void cluster_greedy(const float *T, const oslam_cell *cells, size_t n, fl
         T_out[8] = txz - twy; T_out[9] = tyz + twx; T_out[10] = 1 - (txx + tyy); T_out[11] = ta[2];
         T_out[12] = 0; T_out[13] = 0; T_out[14] = 0; T_out[15] = 1;
     }
+    if (votes_out) *votes_out = cvotes[win];
     free(head); free(member); free(cvotes);
+    return OSLAM_OK;
 }
 
 static double pose_now_ms(void)
@@ -427,6 +439,20 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
                      size_t M, const float *s_xyz, const float *s_nrm, size_t S, float d_dist,
                      int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
                      const float *weights, float T_out[16], float *poses_out)
+{
+    return oslam_pose_stage_ex(cells, n, m_xyz, m_nrm, M, s_xyz, s_nrm, S, d_dist, cpu_clustering, use_l1_norm,
+                               use_averaged_clusters, weights, T_out, poses_out, NULL, NULL, NULL, NULL);
+}
+
+/* the same with the reference's other result fields (include/model.h:100-113): trans_out [n][3] =
+ * transformation_trans after the clustering stage, rots_out [n][4] = transformation_rots (w, x, y, z),
+ * scores_out [n] = vote_counts_out (clustered scores; with cpu_clustering: scores_out[0] = the votes of the
+ * winning cluster), *max_idx_out = max_idx.  Any of them may be NULL. */
+int oslam_pose_stage_ex(const oslam_cell *cells, size_t n, const float *m_xyz, const float *m_nrm,
+                        size_t M, const float *s_xyz, const float *s_nrm, size_t S, float d_dist,
+                        int cpu_clustering, int use_l1_norm, int use_averaged_clusters,
+                        const float *weights, float T_out[16], float *poses_out, float *trans_out, float *rots_out,
+                        float *scores_out, uint32_t *max_idx_out)
 {
     float *poses;
     size_t i;
@@ -458,21 +484,38 @@ int oslam_pose_stage(const oslam_cell *cells, size_t n, const float *m_xyz, cons
         free(fs.idx); free(fs.T); free(fm.idx); free(fm.T);
     }
     t1 = pose_now_ms();
+    if (max_idx_out) *max_idx_out = 0;
     if (cpu_clustering) {
-        cluster_greedy(poses, cells, n, d_dist, POSE_D, T_out);      /* model.cu:262-263 */
+        uint32_t votes = 0;
+        if (cluster_greedy(poses, cells, n, d_dist, POSE_D, T_out, &votes) != OSLAM_OK) {      /* model.cu:262-263 */
+            free(poses);
+            return OSLAM_E_NOMEM;
+        }
+        if (scores_out) scores_out[0] = (float)votes;
     } else if (n > 1) {
         float *trans = (float *)malloc(sizeof(float) * 3 * n);
         float *quat = (float *)malloc(sizeof(float) * 4 * n);
         size_t best;
+        if (!trans || !quat) {
+            free(trans); free(quat); free(poses);
+            return OSLAM_E_NOMEM;
+        }
         for (i = 0; i < n; i++) {
             trans[3 * i] = poses[16 * i + 3];
             trans[3 * i + 1] = poses[16 * i + 7];
             trans[3 * i + 2] = poses[16 * i + 11];
             pose_quat(poses + 16 * i, quat + 4 * i);
         }
-        best = cluster_by_cells(cells, n, trans, quat, d_dist, use_l1_norm, use_averaged_clusters, weights);
+        best = cluster_by_cells(cells, n, trans, quat, d_dist, use_l1_norm, use_averaged_clusters, weights, scores_out);
+        if (best == NO_MEMORY) {
+            free(trans); free(quat); free(poses);
+            return OSLAM_E_NOMEM;
+        }
         memcpy(T_out, poses + 16 * best, 16 * sizeof(float));
         T_out[3] = trans[3 * best]; T_out[7] = trans[3 * best + 1]; T_out[11] = trans[3 * best + 2];
+        if (trans_out) memcpy(trans_out, trans, sizeof(float) * 3 * n);
+        if (rots_out) memcpy(rots_out, quat, sizeof(float) * 4 * n);
+        if (max_idx_out) *max_idx_out = (uint32_t)best;
         free(trans); free(quat);
     }
     t2 = pose_now_ms();

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "oslam_align_local": (_i, [_vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint32), C.POINTER(Stats)]),
     "oslam_align_finish": (_i, [_vp, _vp, _vp, _sz, C.c_uint32, _vp, C.POINTER(Stats)]),
     "oslam_local_peaks": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "oslam_last_result": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint32)]),
+    "oslam_pose_stage_ex": (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oslam_comm_unique_id": (_i, [_vp]),
     "oslam_comm_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     "oslam_comm_destroy": (None, [_vp]),
@@ -344,6 +346,17 @@ class Model:
     @property
     def transformations(self):
         return self.last_cells()[1]
+
+    def last_result(self, scene):
+        """(transformation_trans [n,3], transformation_rots [n,4] wxyz, vote_counts_out [n], max_idx) of the last
+        ppf_lookup against `scene` (model.h:100-113)."""
+        n = C.c_size_t(0)
+        _check(lib().oslam_last_cells(self._h, None, None, 0, C.byref(n)))
+        k = max(n.value, 1)
+        tr, ro, sc = np.zeros((k, 3), np.float32), np.zeros((k, 4), np.float32), np.zeros(k, np.float32)
+        best = C.c_uint32(0)
+        _check(lib().oslam_last_result(self._h, scene._h, _p(tr), _p(ro), _p(sc), k, C.byref(n), C.byref(best)))
+        return tr[: n.value], ro[: n.value], sc[: n.value], int(best.value)
 
     def getHashKeys(self, ref_index):
         out = np.zeros(self.n, np.uint32)

@@ -43,6 +43,32 @@ int main(int argc, char **argv)
                                                  std::vector<std::shared_ptr<Cloud>>{model},
                                                  std::vector<float>{0.05f}, 1, 0.4f, false, false, false, 0, nullptr);
         std::printf("t = %.3f %.3f %.3f\n", res[0][0](0, 3), res[0][0](1, 3), res[0][0](2, 3));
+        // the reference's result fields (model.h:92-113) after a lookup, read the way ppf.cu:74-93 reads them:
+        // the pose they give is the pose oslam_align returned, with and without cpu_clustering
+        for (int cpu = 0; cpu < 2; cpu++) {
+            oslam::Scene<Cloud> sc(scene.get(), 0.05f, 1);
+            oslam::Model<Cloud> mo(model.get(), 0.05f, 0.4f, cpu != 0, false, false);
+            mo.ppf_lookup(&sc);
+            const std::size_t n = mo.voteCodes.size();
+            if (n < 2 || mo.transformations.size() != 16 * n || mo.transformation_trans.size() != n ||
+                mo.transformation_rots.size() != n || mo.vote_counts_out.size() != n || mo.max_idx >= n)
+                return 3;
+            float T[16];
+            if (cpu) {
+                if (mo.cpu_transformations.size() != 1 || mo.cpu_transformations[0].votes == 0) return 4;
+                for (int k = 0; k < 16; k++) T[k] = mo.cpu_transformations[0].pose[k];
+            } else {
+                for (int k = 0; k < 16; k++) T[k] = mo.getTransformations()[mo.max_idx * 16 + k];
+                T[3] = mo.transformation_trans[mo.max_idx].x;
+                T[7] = mo.transformation_trans[mo.max_idx].y;
+                T[11] = mo.transformation_trans[mo.max_idx].z;
+                for (std::size_t i = 0; i < n; i++)
+                    if (mo.vote_counts_out[i] > mo.vote_counts_out[mo.max_idx]) return 5;   // max_idx is the argmax
+            }
+            for (int k = 0; k < 16; k++)
+                if (T[k] != mo.best_T[k]) return 6;
+        }
+        std::printf("fields ok\n");
     }
     return 0;
 }

@@ -349,6 +349,25 @@ def test_full_size_properties(ppf, oracle, built_lib, full_size):
     assert mf.stats["num_votes"] == st1["num_votes"] and mf.stats["max_count"] >= 0.99 * st1["max_count"]
 
 
+def test_result_fields_of_the_reference_model(ppf, oracle, built_lib, case_small):
+    """transformation_trans / transformation_rots / vote_counts_out / max_idx (model.h:100-113) of a lookup equal
+    the oracle's K7 quaternions and translations and its clustering scores; the pose is extracted from them as
+    ppf.cu:74-93 does."""
+    c = case_small
+    sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"])
+    for averaged in (False, True):
+        mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], use_averaged_clusters=averaged)
+        T = mo.ppf_lookup(sc)
+        cells, poses = mo.last_cells()
+        tr, ro, scores, best = mo.last_result(sc)
+        otr, oqu = oracle.mat2transquat(oracle.trans_calc2(cells, c["mp"], c["mn"], c["sp"], c["sn"]))
+        obest, oscores, otr2 = oracle.cluster_gpu_style(cells, otr, oqu, c["d"], use_averaged_clusters=averaged)
+        assert np.array_equal(ro, oqu) and np.array_equal(tr, otr2) and np.array_equal(scores, oscores) and best == obest
+        Tx = poses[best].reshape(4, 4).copy()
+        Tx[:3, 3] = tr[best]
+        assert np.array_equal(Tx, T)
+
+
 def test_cpp_adaptor_runs(ppf, built_lib):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -359,8 +378,9 @@ def test_cpp_adaptor_runs(ppf, built_lib):
                     os.path.join(root, "tests", "native", "pcl_adaptor_check.cpp"), "-o", out,
                     "-L", libdir, "-loslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     r = subprocess.run([out, "run"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    t = [float(x) for x in r.stdout.split("=")[1].split()]
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "fields ok" in r.stdout          # model.h:92-113 result fields give the pose ppf.cu:74-93 extracts
+    t = [float(x) for x in r.stdout.split("=")[1].split()[:3]]
     # the scene is the model shifted by (2, -1, 0); bin-accurate recovery (d_dist = 0.05)
     assert abs(t[0] - 2.0) < 0.3 and abs(t[1] + 1.0) < 0.3 and abs(t[2]) < 0.3
 
