@@ -38,7 +38,7 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = os.path.join(_HERE, "liboracle_ppf.so")
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_ppf.c", "oracle_voxel.c", "oracle_depth.c", "oracle_ppf.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_ppf.c", "oracle_voxel.c", "oracle_depth.c", "oracle_matlab.c", "oracle_ppf.h")]
     if not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
         build()
     L = C.CDLL(path)
@@ -56,6 +56,10 @@ def lib():
     L.orc_votes_fused.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float,
                                   C.c_long, C.c_long, C.c_long, C.c_int, C.POINTER(C.c_size_t),
                                   C.POINTER(Stats)]
+    L.orm_voting_scheme.restype = C.c_uint64
+    L.orm_voting_scheme.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
+    L.orm_d_dist.restype = C.c_double
+    L.orm_d_dist.argtypes = [vp, C.c_int]
     L.orc_fused_create.restype = C.c_void_p
     L.orc_fused_create.argtypes = [vp, vp, C.c_int, C.c_float]
     L.orc_fused_free.argtypes = [vp]
@@ -289,3 +293,41 @@ def align(mp, mn, sp, sn, df, d_dist, thresh=0.4, cpu_clustering=False, use_l1_n
     rc, T = pose_from_cells(cells, mp, mn, sp, sn, d_dist, cpu_clustering, use_l1_norm, use_averaged_clusters)
     st["rc"] = rc
     return T, cells, st
+
+
+# ---- the MATLAB prototype in double precision (oracle_matlab.c; matlab/voting_scheme.m and friends) ----
+def matlab_d_dist(points):
+    """model_description.m:6-15: a tenth of the largest distance from the bounding box's centre."""
+    p = np.ascontiguousarray(points, np.float64)
+    return float(lib().orm_d_dist(_p(p), len(p)))
+
+
+def matlab_voting_scheme(mp, mn, sp, sn, skip, d_dist, eps_bins=1e-4):
+    """voting_scheme.m in double precision (the dictionary key = the four bin indices).  Returns a dict:
+    acc [n_ref, M, 30], argmax_row / argmax_col / max_tots [n_ref] (0-based, -1 = no vote), selected [n_ref]
+    (> 0.9 of the largest maximum), edge_votes [n_ref] (votes within eps_bins of a bin boundary on their
+    way), votes (total)."""
+    mp, mn = np.ascontiguousarray(mp, np.float64), np.ascontiguousarray(mn, np.float64)
+    sp, sn = np.ascontiguousarray(sp, np.float64), np.ascontiguousarray(sn, np.float64)
+    M, S = len(mp), len(sp)
+    n_ref = (S + skip - 1) // skip
+    acc = np.zeros((n_ref, M, 30), np.uint32)
+    row, col = np.zeros(n_ref, np.int32), np.zeros(n_ref, np.int32)
+    mx, sel, ev = np.zeros(n_ref, np.uint32), np.zeros(n_ref, np.uint8), np.zeros(n_ref, np.uint64)
+    votes = lib().orm_voting_scheme(_p(mp), _p(mn), M, _p(sp), _p(sn), S, int(skip), float(d_dist), float(eps_bins),
+                                    _p(acc), _p(row), _p(col), _p(mx), _p(sel), _p(ev))
+    if votes == 2 ** 64 - 1:
+        raise MemoryError("orm_voting_scheme")
+    return dict(acc=acc, argmax_row=row, argmax_col=col, max_tots=mx, selected=sel.astype(bool), edge_votes=ev, votes=int(votes))
+
+
+def matlab_argmax(acc2d):
+    """[Y_rows, I_row] = max(A); [max_tot, I_col] = max(Y_rows) (voting_scheme.m:83-88) on one [M, 30] slice:
+    (row, col, max) with MATLAB's first-maximum rule, (-1, -1, 0) for an empty slice."""
+    a = np.asarray(acc2d)
+    colmax = a.max(axis=0)
+    if colmax.max() == 0:
+        return -1, -1, 0
+    c = int(np.argmax(colmax))                # first column with the largest maximum
+    r = int(np.argmax(a[:, c]))               # first row of that column
+    return r, c, int(colmax[c])

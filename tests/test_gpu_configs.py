@@ -257,3 +257,40 @@ def test_recall_vs_occlusion_protocol_on_device(ppf, built_lib, synth):
     assert table[0]["recall"] == 1.0                      # nothing cut away: both found
     assert len(cum) == 4 and cum[0] == 1.0 and cum[1] == 1.0
     assert table[1]["recall"] <= table[0]["recall"]
+
+
+@pytest.mark.parametrize("M,S,seed,noise", [(150, 360, 2071, 0.02), (300, 700, 2072, 0.1)])
+def test_matlab_argmax_set_on_device(ppf, oracle, built_lib, synth, M, S, seed, noise):
+    """SURVEY.md 8 row a23 on the device: the HIP accumulator of every reference point, read the way the MATLAB
+    prototype reads its own (voting_scheme.m:83-94: first maximum in column order per reference point, then the
+    reference points above 0.9 of the largest), against the double-precision restatement of the prototype
+    (oracle/oracle_matlab.c).  Slices without a bin-edge case are identical; where the margin exceeds the
+    counted edge cases the argmax is the same; the selected set is the same."""
+    mp, mn = synth.make_model(0, M)
+    d = synth.d_dist_for(mp, 0.05)
+    sp, sn, _ = synth.make_scene([0], S, seed, instance_points=M, noise_sigma=noise * d)
+    skip = 5
+    R = oracle.matlab_voting_scheme(mp, mn, sp, sn, skip, d)
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=skip)
+    mo = ppf.Model(mp, mn, d_dist=d)
+    maxima, decided, identical = [], 0, 0
+    for t, r in enumerate(range(0, S, skip)):
+        a = mo.vote_accumulator(sc, r)
+        f = a[:, :30].astype(np.int64)
+        f[:, 29] += a[:, 30]                                  # voting_scheme.m:74 puts alpha + pi == 2 pi into the last bin
+        ev = int(R["edge_votes"][t])
+        assert int(np.abs(f - R["acc"][t].astype(np.int64)).sum()) <= 2 * ev, t
+        identical += int(ev == 0)
+        row, col, mx = oracle.matlab_argmax(f)
+        maxima.append(mx)
+        top2 = np.sort(f.ravel())[-2:]
+        if top2[1] - top2[0] > 2 * ev:
+            decided += 1
+            assert (row, col, mx) == (R["argmax_row"][t], R["argmax_col"][t], R["max_tots"][t]), t
+    assert decided >= 10 and identical >= len(maxima) // 2
+    maxima = np.float64(maxima)
+    selected = maxima / maxima.max() > 0.9                    # voting_scheme.m:90-92
+    # the selection can only differ where a maximum sits within the edge cases' reach of the 0.9 line
+    near = np.abs(maxima - 0.9 * maxima.max()) <= 2 * R["edge_votes"].astype(np.float64) + 1
+    assert np.array_equal(selected[~near], R["selected"][~near])
+    assert selected.any()
