@@ -141,6 +141,21 @@ int oslam_align(oslam_model *m, oslam_scene *s, float T_rowmajor[16], oslam_stat
  * ahead of time so that the first registration is as fast as the following ones. */
 int oslam_align_prepare(oslam_model *m, oslam_scene *s);
 
+/* Model database: what the loop of src/cuda/ppf.cu:57-100 becomes when the models stay resident.  The
+ * database borrows the models (destroy it before them).  Models that share d_dist, device and vote mode
+ * form a group with one union table of pair keys: per frame the scene pass (pair keys, probe, hit sort)
+ * runs once per group instead of once per model, and every member votes from the same hit lists with
+ * its own buckets.  Models with a d_dist of their own are groups of one.  A database made with ONE
+ * d_dist for all models (the scene then also needs one voxel grid only) gets the whole benefit.
+ * oslam_db_align: T_out[j*16..] = pose of model j (zeros when nothing matched), stats[j] (may be NULL)
+ * its counters; in a group of several, num_hits counts the pairs whose key is in ANY member and the
+ * kernel times are the group's, shared out evenly. */
+typedef struct oslam_db oslam_db;
+int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out);
+void oslam_db_destroy(oslam_db *db);
+int oslam_db_align(oslam_db *db, oslam_scene *s, float *T_out, oslam_stats *stats);
+int oslam_db_size(const oslam_db *db, size_t *n_models, size_t *n_groups);
+
 /* ppf_registration (include/ppf.h:9-15, src/cuda/ppf.cu:29-106): every scene
  * against every model; T_out[(i*n_models + j)*16 ..] = pose of model j in
  * scene i.  model_weights is accepted and ignored, as in the reference

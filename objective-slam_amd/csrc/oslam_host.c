@@ -149,6 +149,8 @@ struct oslam_model {
     size_t pose_cap;
     /* host copy of the table for the bucket tap */
     oslamk_slot *h_slots;
+    /* member of a database group: table.ukeys / reach belong to the group (oslam_db) */
+    int shared_union;
 };
 
 struct oslam_scene {
@@ -309,8 +311,8 @@ void oslam_model_destroy(oslam_model *m)
     if (m->ent.e4) (void)hipFree(m->ent.e4);
     if (m->ent.uv) (void)hipFree(m->ent.uv);
     if (m->ent.mi) (void)hipFree(m->ent.mi);
-    if (m->table.ukeys) (void)hipFree(m->table.ukeys);
-    if (m->table.reach) (void)hipFree(m->table.reach);
+    if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
+    if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_union) (void)hipFree(m->d_union);
@@ -325,6 +327,34 @@ void oslam_model_destroy(oslam_model *m)
     free(m->last_poses);
     free(m->h_slots);
     free(m);
+}
+
+/* table.ukeys (every distinct key of the model once, at most a quarter full; `distinct` = an upper bound of
+ * their number) and table.reach (the distance bins that can produce a key); d_n_keys / d_overflow: device words */
+static int build_union(oslam_model *m, uint32_t distinct, uint32_t *d_n_keys, uint32_t *d_overflow)
+{
+    int rc = OSLAM_OK;
+    uint32_t lg = 16;
+    while ((1u << lg) < 4u * distinct && lg < OSLAMK_RUN_SHIFT) lg++;
+    if ((1u << lg) < 2u * distinct) return fail(OSLAM_E_LIMIT, "more distinct pair keys than the union table can index");
+    if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
+    if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
+    m->table.ukeys = NULL;
+    m->table.reach = NULL;
+    m->shared_union = 0;
+    m->table.ucap = 1u << lg;
+    m->table.ushift = 32 - lg;
+    HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)m->table.ucap));
+    HIPCHK(hipMemsetAsync(m->table.ukeys, 0, sizeof(uint32_t) * (size_t)m->table.ucap, (hipStream_t)g_stream));
+    HIPCHK(hipMemsetAsync(d_overflow, 0, sizeof(uint32_t), (hipStream_t)g_stream));
+    HIPCHK(hipMemsetAsync(d_n_keys, 0, sizeof(uint32_t), (hipStream_t)g_stream));
+    KCHK(oslamk_union_build(m->table, d_n_keys, d_overflow, g_stream));
+    /* which distance bins can produce a model key at all (lets the scene-key kernel drop far pairs) */
+    HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
+    HIPCHK(hipMemsetAsync(m->table.reach, 0, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), (hipStream_t)g_stream));
+    KCHK(oslamk_reach_build(m->table, m->d_dist, g_stream));
+done:
+    return rc;
 }
 
 /* table.uinfo: the bucket of every union-table slot in every slice (what the vote kernel reads) */
@@ -398,20 +428,10 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     KCHK(oslamk_table_scan(m->table, d_small + 65, g_stream));
     /* union of all slices' keys, kept at most a quarter full */
     {
-        uint32_t sum = 0, lg = 16;
+        uint32_t sum = 0;
         for (s = 0; s < n_slices; s++) sum += h_small[s];
-        while ((1u << lg) < 4u * sum && lg < OSLAMK_RUN_SHIFT) lg++;
-        if ((1u << lg) < 2u * sum) { rc = fail(OSLAM_E_LIMIT, "more distinct pair keys than the union table can index"); goto done; }
-        m->table.ucap = 1u << lg;
-        m->table.ushift = 32 - lg;
-        HIPCHK(hipMalloc((void **)&m->table.ukeys, sizeof(uint32_t) * (size_t)m->table.ucap));
-        HIPCHK(hipMemsetAsync(m->table.ukeys, 0, sizeof(uint32_t) * (size_t)m->table.ucap, (hipStream_t)g_stream));
-        HIPCHK(hipMemsetAsync(d_small + 64, 0, sizeof(uint32_t), (hipStream_t)g_stream));
-        KCHK(oslamk_union_build(m->table, d_small + 66, d_small + 64, g_stream));
-        /* which distance bins can produce a model key at all (lets the scene-key kernel drop far pairs) */
-        HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
-        HIPCHK(hipMemsetAsync(m->table.reach, 0, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), (hipStream_t)g_stream));
-        KCHK(oslamk_reach_build(m->table, m->d_dist, g_stream));
+        rc = build_union(m, sum, d_small + 66, d_small + 64);
+        if (rc != OSLAM_OK) goto done;
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
     HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
@@ -1009,12 +1029,16 @@ static int batch_extent(const uint32_t *keep, int first, int n_ref, size_t limit
 /* The kernels of one registration (or of one reference point for the accumulator tap): count, then per
  * batch scene keys -> hit sort -> votes.  d_ref_idx / d_tsg: the reference points and their frame rows.
  * The caller holds the pool of the device. */
-static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, const uint32_t *d_ref_idx,
-                          const float *d_tsg, int n_ref, uint32_t fixed_gmax, uint32_t *acc_dump,
-                          oslamk_counters *cnt, float *ms_out, float *ms_vote_kernel, float *ms_key_kernel,
-                          uint32_t *launches, uint64_t *probed)
+static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, oslam_scene *s, const uint32_t *d_ref_idx,
+                           const float *d_tsg, int n_ref, uint32_t fixed_gmax, uint32_t *acc_dump,
+                           oslamk_counters *cnt, float *ms_out, float *ms_vote_kernel, float *ms_key_kernel,
+                           uint32_t *launches, uint64_t *probed)
 {
-    int rc = OSLAM_OK, first, nb = 0, i;
+    /* ms[0..nm): models that share one union table and d_dist (a database group, or one model): the scene
+     * pass -- count, keys, hit sort -- runs once for all of them, then each model votes with its own buckets.
+     * cnt[nm]; the vote-kernel time is the sum over the models. */
+    oslam_model *m = ms[0];
+    int rc = OSLAM_OK, first, nb = 0, i, j;
     oslamk_vote_args a;
     hipStream_t st = (hipStream_t)g_stream;
     hipEvent_t *ev;
@@ -1049,7 +1073,7 @@ static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, co
     a.acc_dump = acc_dump;
     a.dump_ref = acc_dump ? 0 : -1;
     a.mode = (m->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
-    HIPCHK(hipMemsetAsync(m->d_counters, 0, sizeof(oslamk_counters), st));
+    for (j = 0; j < nm; j++) HIPCHK(hipMemsetAsync(ms[j]->d_counters, 0, sizeof(oslamk_counters), st));
     HIPCHK(hipEventRecord(ev[0], st));
     /* 1. demand: pairs within reach, per reference point */
     if (n_ref > 0) {
@@ -1103,7 +1127,18 @@ static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, co
             KCHK(oslamk_scene_hits(&a, g_stream));
             KCHK(oslamk_sort_hits(&a, g_stream));
             if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb + 1], st));
-            KCHK(oslamk_vote(&a, g_stream));
+            for (j = 0; j < nm; j++) {
+                const oslam_model *mj = ms[j];
+                a.table.uinfo = mj->table.uinfo;          /* its buckets, under the shared union slots */
+                a.table.n_slices = mj->table.n_slices;
+                a.ent = mj->ent;
+                a.thresh = mj->params.vote_count_threshold;
+                a.counters = mj->d_counters;
+                a.out = mj->d_out;
+                a.out_cap = mj->out_cap;
+                a.mode = (mj->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
+                KCHK(oslamk_vote(&a, g_stream));
+            }
             if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb + 2], st));
             if (launches) *launches += 1;
             pos += (size_t)n + 1;
@@ -1111,7 +1146,7 @@ static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, co
         }
     }
     HIPCHK(hipEventRecord(ev[1], st));
-    HIPCHK(hipMemcpyAsync(cnt, m->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
+    for (j = 0; j < nm; j++) HIPCHK(hipMemcpyAsync(&cnt[j], ms[j]->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, ev[0], ev[1]));
     for (i = 0; i < nb && i < MAX_BATCH_EVENTS; i++) {
@@ -1123,6 +1158,17 @@ static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, co
     }
 done:
     return rc;
+}
+
+static int run_votes_refs(scratch_pool *pool, oslam_model *m, oslam_scene *s, const uint32_t *d_ref_idx,
+                          const float *d_tsg, int n_ref, uint32_t fixed_gmax, uint32_t *acc_dump,
+                          oslamk_counters *cnt, float *ms_out, float *ms_vote_kernel, float *ms_key_kernel,
+                          uint32_t *launches, uint64_t *probed)
+{
+    oslam_model *one[1];
+    one[0] = m;
+    return run_votes_group(pool, one, 1, s, d_ref_idx, d_tsg, n_ref, fixed_gmax, acc_dump, cnt, ms_out, ms_vote_kernel,
+                           ms_key_kernel, launches, probed);
 }
 
 static int run_votes(scratch_pool *pool, oslam_model *m, oslam_scene *s, uint32_t fixed_gmax, oslamk_counters *cnt,
@@ -1723,6 +1769,231 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------------
+ * Model database (src/cuda/ppf.cu:57-100: the reference loops scenes x models and rebuilds
+ * both every time).  Models that share d_dist (and device and vote mode) form a group with ONE union table:
+ * the scene pass -- count, pair keys, probe, hit sort -- then runs once per group and frame instead of once
+ * per model, every model votes from the same hit lists with its own buckets (table.uinfo under the group's
+ * slots), and nothing waits on the host between the models of a group.  Models with a d_dist of their own
+ * are groups of one and take the single-model path.
+ * ---------------------------------------------------------------------- */
+typedef struct db_group {
+    int n;
+    size_t *members;                  /* indices into db->models */
+    uint32_t *ukeys, *reach;          /* the group's union table and reachable-distance bitset (n > 1) */
+} db_group;
+
+struct oslam_db {
+    int dev;
+    size_t n;
+    oslam_model **models;             /* borrowed */
+    int n_groups;
+    db_group *groups;
+};
+
+static int same_group(const oslam_model *a, const oslam_model *b)
+{
+    return a->dev == b->dev && a->d_dist == b->d_dist && a->params.vote_mode == b->params.vote_mode;
+}
+
+void oslam_db_destroy(oslam_db *db)
+{
+    int g, k;
+    uint32_t *d_small = NULL;
+    if (!db) return;
+    (void)hipSetDevice(db->dev);
+    (void)hipMalloc((void **)&d_small, 2 * sizeof(uint32_t));
+    for (g = 0; g < db->n_groups; g++) {
+        db_group *gr = &db->groups[g];
+        if (gr->n > 1) {
+            /* the members get a union table of their own back */
+            for (k = 0; k < gr->n; k++) {
+                oslam_model *m = db->models[gr->members[k]];
+                if (d_small && build_union(m, (uint32_t)(m->num_model_keys ? m->num_model_keys - 1 : 0), d_small, d_small + 1) == OSLAM_OK)
+                    (void)build_uinfo(m);
+            }
+            (void)hipStreamSynchronize((hipStream_t)g_stream);
+            if (gr->ukeys) (void)hipFree(gr->ukeys);
+            if (gr->reach) (void)hipFree(gr->reach);
+        }
+        free(gr->members);
+    }
+    if (d_small) (void)hipFree(d_small);
+    free(db->groups);
+    free(db->models);
+    free(db);
+}
+
+int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
+{
+    int rc = OSLAM_OK, g, k;
+    size_t j;
+    oslam_db *db;
+    uint32_t *d_small = NULL, h_small[2];
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (!models || n == 0) return fail(OSLAM_E_INVALID, "empty database");
+    for (j = 0; j < n; j++) {
+        if (!models[j]) return fail(OSLAM_E_INVALID, "NULL model");
+        if (models[j]->shared_union) return fail(OSLAM_E_INVALID, "a model can be in one database at a time");
+        if (models[j]->dev != models[0]->dev) return fail(OSLAM_E_INVALID, "the models of a database live on one device");
+    }
+    db = (oslam_db *)calloc(1, sizeof *db);
+    if (!db) return fail(OSLAM_E_NOMEM, "host allocation failed");
+    db->dev = models[0]->dev;
+    db->n = n;
+    db->models = (oslam_model **)malloc(sizeof *db->models * n);
+    db->groups = (db_group *)calloc(n, sizeof *db->groups);
+    if (!db->models || !db->groups) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    memcpy(db->models, models, sizeof *db->models * n);
+    if (hipSetDevice(db->dev) != hipSuccess) { rc = fail(OSLAM_E_DEVICE, "hipSetDevice failed"); goto done; }
+    for (j = 0; j < n; j++) {
+        for (g = 0; g < db->n_groups; g++)
+            if (same_group(models[db->groups[g].members[0]], models[j])) break;
+        if (g == db->n_groups) {
+            db->groups[g].members = (size_t *)malloc(sizeof(size_t) * n);
+            if (!db->groups[g].members) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+            db->n_groups++;
+        }
+        db->groups[g].members[db->groups[g].n++] = j;
+    }
+    HIPCHK(hipMalloc((void **)&d_small, 2 * sizeof(uint32_t)));
+    for (g = 0; g < db->n_groups; g++) {
+        db_group *gr = &db->groups[g];
+        oslamk_table t;
+        uint64_t distinct = 0;
+        uint32_t lg = 16;
+        if (gr->n < 2) continue;
+        for (k = 0; k < gr->n; k++) distinct += models[gr->members[k]]->num_model_keys;
+        while (((uint64_t)1 << lg) < 4u * distinct && lg < OSLAMK_RUN_SHIFT) lg++;
+        if (((uint64_t)1 << lg) < 2u * distinct) { rc = fail(OSLAM_E_LIMIT, "more distinct pair keys in the group than a union table can index"); goto done; }
+        HIPCHK(hipMalloc((void **)&gr->ukeys, sizeof(uint32_t) << lg));
+        HIPCHK(hipMalloc((void **)&gr->reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
+        HIPCHK(hipMemsetAsync(gr->ukeys, 0, sizeof(uint32_t) << lg, (hipStream_t)g_stream));
+        HIPCHK(hipMemsetAsync(gr->reach, 0, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), (hipStream_t)g_stream));
+        HIPCHK(hipMemsetAsync(d_small, 0, 2 * sizeof(uint32_t), (hipStream_t)g_stream));
+        /* every member's keys into the group's table */
+        for (k = 0; k < gr->n; k++) {
+            t = models[gr->members[k]]->table;
+            t.ukeys = gr->ukeys;
+            t.ucap = 1u << lg;
+            t.ushift = 32 - lg;
+            KCHK(oslamk_union_build(t, d_small, d_small + 1, g_stream));
+        }
+        t.reach = gr->reach;
+        KCHK(oslamk_reach_build(t, models[gr->members[0]]->d_dist, g_stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+        HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
+        if (h_small[1]) { rc = fail(OSLAM_E_LIMIT, "union key table overflow"); goto done; }
+        /* the members look their buckets up under the group's slots from now on */
+        for (k = 0; k < gr->n; k++) {
+            oslam_model *m = models[gr->members[k]];
+            (void)hipFree(m->table.ukeys);
+            (void)hipFree(m->table.reach);
+            m->table.ukeys = gr->ukeys;
+            m->table.reach = gr->reach;
+            m->table.ucap = 1u << lg;
+            m->table.ushift = 32 - lg;
+            m->shared_union = 1;
+            rc = build_uinfo(m);
+            if (rc != OSLAM_OK) goto done;
+        }
+        HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    }
+done:
+    if (d_small) (void)hipFree(d_small);
+    if (rc != OSLAM_OK) { oslam_db_destroy(db); return rc; }
+    *out = db;
+    return OSLAM_OK;
+}
+
+int oslam_db_align(oslam_db *db, oslam_scene *s, float *T_out, oslam_stats *stats)
+{
+    int rc = OSLAM_OK, g, k, first_err = OSLAM_OK;
+    scratch_pool *pool;
+    oslamk_counters *cnt = NULL;
+    oslam_model **ms = NULL;
+    double t0 = now_ms();
+    if (!db || !s || !T_out) return fail(OSLAM_E_INVALID, "NULL argument");
+    memset(T_out, 0, sizeof(float) * 16 * db->n);
+    if (stats) memset(stats, 0, sizeof *stats * db->n);
+    for (k = 0; k < (int)db->n; k++) {
+        rc = check_pair(db->models[k], s);
+        if (rc != OSLAM_OK) return rc;
+    }
+    if (hipSetDevice(db->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    cnt = (oslamk_counters *)malloc(sizeof *cnt * db->n);
+    ms = (oslam_model **)malloc(sizeof *ms * db->n);
+    if (!cnt || !ms) { free(cnt); free(ms); return fail(OSLAM_E_NOMEM, "host allocation failed"); }
+    pool = pool_lock(db->dev);
+    if (!pool) { free(cnt); free(ms); return fail(OSLAM_E_LIMIT, "device ordinal too large"); }
+    g_cur_pool = pool;
+    for (g = 0; g < db->n_groups && rc == OSLAM_OK; g++) {
+        db_group *gr = &db->groups[g];
+        float ms_all = 0.0f, msv = 0.0f, msk = 0.0f;
+        uint32_t launches = 0;
+        uint64_t probed = 0;
+        for (k = 0; k < gr->n; k++) ms[k] = db->models[gr->members[k]];
+        if (gr->n > 1) {
+            /* one scene pass, every member's votes behind it */
+            rc = run_votes_group(pool, ms, gr->n, s, s->d_ref_idx, s->d_tsg, s->n_ref, 0, NULL, cnt, &ms_all, &msv, &msk,
+                                 &launches, &probed);
+            if (rc != OSLAM_OK) break;
+        }
+        for (k = 0; k < gr->n && rc == OSLAM_OK; k++) {
+            oslam_model *m = ms[k];
+            oslam_stats local, *st = stats ? &stats[gr->members[k]] : &local;
+            float *T = T_out + 16 * gr->members[k];
+            size_t n = 0;
+            int arc;
+            memset(st, 0, sizeof *st);
+            if (gr->n > 1 && cnt[k].out_count <= m->out_cap) {
+                n = cnt[k].out_count;
+                st->num_scene_ppfs = (uint64_t)s->n_ref * (uint64_t)(s->c.n - 1);
+                st->num_hits = cnt[k].hits;                /* of the group's pass: pairs whose key is in some member */
+                st->num_votes = cnt[k].votes;
+                st->num_unique_votes = cnt[k].nonzero_cells;
+                st->num_model_keys = m->num_model_keys;
+                st->max_count = cnt[k].gmax;
+                st->num_emitted = cnt[k].out_count;
+                st->ms_vote = ms_all / (float)gr->n;       /* the group's kernels, shared out evenly */
+                st->ms_vote_kernel = msv / (float)gr->n;
+                st->ms_key_kernel = msk / (float)gr->n;
+                st->vote_launches = launches;
+                st->num_pairs_probed = probed;
+                st->scratch_bytes = pool->bytes;
+                st->num_entries_streamed = cnt[k].entries;
+                st->num_items = cnt[k].items;
+                if (n && !(pose_gpu_from(m) && n >= pose_gpu_from(m)))
+                    HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * n, hipMemcpyDeviceToHost));
+                arc = OSLAM_OK;
+            } else {
+                /* a group of one -- or a member whose peak records did not fit its buffer: the single-model path */
+                arc = vote_and_fetch(pool, m, s, &cnt[k], &n, st, pose_gpu_from(m));
+            }
+            if (arc == OSLAM_OK) arc = finish_after_votes(m, s, n, cnt[k].gmax, T, st);
+            if (arc != OSLAM_OK && arc != OSLAM_E_NO_VOTES) rc = arc;
+            else if (arc == OSLAM_E_NO_VOTES && first_err == OSLAM_OK) first_err = arc;
+            st->ms_total = (float)(now_ms() - t0);
+        }
+    }
+done:
+    g_cur_pool = NULL;
+    pool_unlock(pool);
+    free(cnt);
+    free(ms);
+    (void)first_err;                  /* a model without votes leaves its T zero, as oslam_ppf_registration does */
+    return rc;
+}
+
+int oslam_db_size(const oslam_db *db, size_t *n_models, size_t *n_groups)
+{
+    if (!db) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (n_models) *n_models = db->n;
+    if (n_groups) *n_groups = (size_t)db->n_groups;
+    return OSLAM_OK;
+}
+
 int oslam_ppf_registration(const float *const *scene_xyz, const float *const *scene_nrm,
                            const size_t *scene_n, size_t n_scenes, const float *const *model_xyz,
                            const float *const *model_nrm, const size_t *model_n, size_t n_models,
@@ -1733,6 +2004,7 @@ int oslam_ppf_registration(const float *const *scene_xyz, const float *const *sc
 {
     oslam_params p;
     oslam_model **models = NULL;
+    oslam_db *db = NULL;
     size_t i, j;
     int rc = OSLAM_OK;
     (void)model_weights;                       /* ignored by the reference too: ppf.cu:35 */
@@ -1751,17 +2023,17 @@ int oslam_ppf_registration(const float *const *scene_xyz, const float *const *sc
     /* models are built once and stay resident (the reference rebuilds per pair) */
     for (j = 0; j < n_models && rc == OSLAM_OK; j++)
         rc = oslam_model_create(model_xyz[j], model_nrm[j], model_n[j], stride_bytes, model_d_dists[j], &p, &models[j]);
-    for (i = 0; i < n_scenes && rc == OSLAM_OK; i++) {
+    if (rc == OSLAM_OK && n_models) rc = oslam_db_create(models, n_models, &db);
+    for (i = 0; i < n_scenes && rc == OSLAM_OK && n_models; i++) {
         /* one scene object for all models: the reference prepares the scene per model because its
-         * pair keys depend on the model's d_dist (ppf.cu:64-67); here they are made inside the align */
+         * pair keys depend on the model's d_dist (ppf.cu:64-67); here they are made inside the align,
+         * once per group of models that share a d_dist */
         oslam_scene *sc = NULL;
         rc = oslam_scene_create(scene_xyz[i], scene_nrm[i], scene_n[i], stride_bytes, 0.0f, df, &p, &sc);
-        for (j = 0; j < n_models && rc == OSLAM_OK; j++) {
-            int arc = oslam_align(models[j], sc, T_out + 16 * (i * n_models + j), NULL);
-            if (arc != OSLAM_OK && arc != OSLAM_E_NO_VOTES) rc = arc;
-        }
+        if (rc == OSLAM_OK) rc = oslam_db_align(db, sc, T_out + 16 * (i * n_models), NULL);
         oslam_scene_destroy(sc);
     }
+    oslam_db_destroy(db);
     for (j = 0; j < n_models; j++) oslam_model_destroy(models[j]);
     free(models);
     return rc;

@@ -88,6 +88,10 @@ _SIGNATURES = {
     "oslam_comm_destroy": (None, [_vp]),
     "oslam_align_multi": (_i, [_vp, _vp, _vp, _vp, C.POINTER(Stats)]),
     "oslam_release_scratch": (_i, [_i]),
+    "oslam_db_create": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "oslam_db_destroy": (None, [_vp]),
+    "oslam_db_align": (_i, [_vp, _vp, _vp, _vp]),
+    "oslam_db_size": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "oslam_scene_keys": (_i, [_vp, _sz, _vp]),
     "oslam_model_keys": (_i, [_vp, _sz, _vp]),
     "oslam_model_bucket": (_i, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
@@ -383,9 +387,50 @@ class Model:
         return acc
 
     def close(self):
+        if getattr(self, "_db", None) is not None:
+            self._db.close()
         if self._h:
             lib().oslam_model_destroy(self._h)
             self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Database:
+    """Resident model database (oslam_db): models with one d_dist share the scene pass of every frame."""
+
+    def __init__(self, models):
+        self.models = list(models)
+        self._h = C.c_void_p(0)
+        arr = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
+        _check(lib().oslam_db_create(arr, len(self.models), C.byref(self._h)))
+        n, g = C.c_size_t(0), C.c_size_t(0)
+        _check(lib().oslam_db_size(self._h, C.byref(n), C.byref(g)))
+        self.n_groups = g.value
+        for m in self.models:              # the database borrows its models: it goes first
+            m._db = self
+
+    def align(self, scene):
+        """-> (poses [n,4,4], list of per-model counters)."""
+        n = len(self.models)
+        T = np.zeros((n, 4, 4), np.float32)
+        st = (Stats * n)()
+        _check(lib().oslam_db_align(self._h, scene._h, _p(T), st))
+        stats = [s.asdict() for s in st]
+        for m, t, d in zip(self.models, T, stats):
+            m.best_T, m.stats = t, d
+        return T, stats
+
+    def close(self):
+        if self._h:
+            lib().oslam_db_destroy(self._h)
+            self._h = C.c_void_p(0)
+            for m in self.models:
+                m._db = None
 
     def __del__(self):
         try:
