@@ -223,6 +223,41 @@ done:
     return rc;
 }
 
+/* A cloud that already lies in HBM as [n][6] (x y z nx ny nz per point: what the depth and voxel kernels
+ * write): the structure of arrays is made on the device; one copy comes back for the host-side arrays
+ * (reference frames, pose stage). */
+static int cloud_from_device6(cloud_buf *c, const float *d_aos6, size_t n)
+{
+    int rc = OSLAM_OK;
+    float *h6 = NULL;
+    size_t i;
+    memset(c, 0, sizeof *c);
+    c->n = (int)n;
+    c->h_xyz = (float *)malloc(sizeof(float) * 3 * n);
+    c->h_nrm = (float *)malloc(sizeof(float) * 3 * n);
+    h6 = (float *)malloc(sizeof(float) * 6 * n);
+    if (!c->h_xyz || !c->h_nrm || !h6) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    HIPCHK(hipMalloc((void **)&c->d_soa, sizeof(float) * 6 * n));
+    KCHK(oslamk_aos6_to_soa(d_aos6, n, c->d_soa, g_stream));
+    HIPCHK(hipMemcpyAsync(h6, d_aos6, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, (hipStream_t)g_stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    for (i = 0; i < n; i++) {
+        memcpy(c->h_xyz + 3 * i, h6 + 6 * i, 3 * sizeof(float));
+        memcpy(c->h_nrm + 3 * i, h6 + 6 * i + 3, 3 * sizeof(float));
+    }
+    c->k.px = c->d_soa;
+    c->k.py = c->d_soa + n;
+    c->k.pz = c->d_soa + 2 * n;
+    c->k.nx = c->d_soa + 3 * n;
+    c->k.ny = c->d_soa + 4 * n;
+    c->k.nz = c->d_soa + 5 * n;
+    c->k.n = (int)n;
+done:
+    free(h6);
+    if (rc != OSLAM_OK) cloud_free(c);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------ */
 int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride_bytes, float leaf,
                      int dev, float *xyz_out, float *nrm_out, size_t cap, size_t *n_out)
@@ -742,8 +777,9 @@ void oslam_scene_destroy(oslam_scene *s)
     free(s);
 }
 
-int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
-                       float d_dist, unsigned df, const oslam_params *params, oslam_scene **out)
+/* Scene::Scene (scene.cu:24-55) from host buffers (xyz != NULL) or from a cloud that lies in HBM as [n][6] */
+static int scene_create_any(const float *xyz, const float *nrm, size_t stride_bytes, const float *d_aos6, size_t n,
+                            float d_dist, unsigned df, const oslam_params *params, oslam_scene **out)
 {
     int rc = OSLAM_OK;
     oslam_scene *s = NULL;
@@ -751,9 +787,8 @@ int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stri
     float *h_tsg = NULL;
     size_t n_all, t;
 
-    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
     *out = NULL;
-    if (!xyz || !nrm || stride_bytes < 12 || !(d_dist >= 0.0f) || df == 0) return fail(OSLAM_E_INVALID, "bad scene arguments");
+    if (!(d_dist >= 0.0f) || df == 0) return fail(OSLAM_E_INVALID, "bad scene arguments");
     if (n < 2) return fail(OSLAM_E_INVALID, "scene needs at least 2 points");
     if (n > 0x7fffffffu) return fail(OSLAM_E_LIMIT, "scene too large");
     if (params) p = *params; else oslam_params_default(&p);
@@ -762,7 +797,7 @@ int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stri
     if (!s) return fail(OSLAM_E_NOMEM, "host allocation failed");
     rc = pick_device(p.dev, &s->dev);
     if (rc != OSLAM_OK) goto done;
-    rc = cloud_upload(&s->c, xyz, nrm, n, stride_bytes);
+    rc = d_aos6 ? cloud_from_device6(&s->c, d_aos6, n) : cloud_upload(&s->c, xyz, nrm, n, stride_bytes);
     if (rc != OSLAM_OK) goto done;
     s->d_dist = d_dist;
     s->df = df;
@@ -793,6 +828,15 @@ done:
     return OSLAM_OK;
 }
 
+int oslam_scene_create(const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
+                       float d_dist, unsigned df, const oslam_params *params, oslam_scene **out)
+{
+    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
+    *out = NULL;
+    if (!xyz || !nrm || stride_bytes < 12) return fail(OSLAM_E_INVALID, "bad scene arguments");
+    return scene_create_any(xyz, nrm, stride_bytes, NULL, n, d_dist, df, params, out);
+}
+
 int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int height, const oslam_camera *cam,
                            float leaf, float d_dist, unsigned df, const oslam_params *params, oslam_scene **out,
                            size_t *n_points_out)
@@ -800,10 +844,10 @@ int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int h
     int rc = OSLAM_OK, k, devsel;
     oslam_params p;
     void *d_img = NULL;
-    float *d_pts6 = NULL, *d_soa = NULL, *d_vox6 = NULL, *h6 = NULL, *h_xyz = NULL, *h_nrm = NULL;
+    float *d_pts6 = NULL, *d_soa = NULL, *d_vox6 = NULL;
     const float *d_final;
     uint32_t np = 0, nv = 0;
-    size_t i, n_pix, px_bytes, n_final;
+    size_t n_pix, px_bytes, n_final;
     if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
     *out = NULL;
     if (n_points_out) *n_points_out = 0;
@@ -839,21 +883,10 @@ int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int h
         n_final = nv;
     }
     if (n_final < 2) { rc = fail(OSLAM_E_INVALID, "the depth image leaves fewer than 2 scene points"); goto done; }
-    h6 = (float *)malloc(sizeof(float) * 6 * n_final);
-    h_xyz = (float *)malloc(sizeof(float) * 3 * n_final);
-    h_nrm = (float *)malloc(sizeof(float) * 3 * n_final);
-    if (!h6 || !h_xyz || !h_nrm) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
-    HIPCHK(hipMemcpy(h6, d_final, sizeof(float) * 6 * n_final, hipMemcpyDeviceToHost));
-    for (i = 0; i < n_final; i++) {
-        memcpy(h_xyz + 3 * i, h6 + 6 * i, 3 * sizeof(float));
-        memcpy(h_nrm + 3 * i, h6 + 6 * i + 3, 3 * sizeof(float));
-    }
-    rc = oslam_scene_create(h_xyz, h_nrm, n_final, 12, d_dist, df, &p, out);
+    /* the scene's arrays are made from the cloud where it lies; one copy comes back for the host's reference frames */
+    rc = scene_create_any(NULL, NULL, 0, d_final, n_final, d_dist, df, &p, out);
     if (rc == OSLAM_OK && n_points_out) *n_points_out = n_final;
 done:
-    free(h6);
-    free(h_xyz);
-    free(h_nrm);
     if (d_img) (void)hipFree(d_img);
     if (d_pts6) (void)hipFree(d_pts6);
     if (d_soa) (void)hipFree(d_soa);

@@ -95,3 +95,33 @@ def finish_on_host(cells, global_max, m_pts, m_nrm, s_pts, s_nrm, d_dist, vote_c
     T, _ = ppf.pose_stage(buf, m_pts, m_nrm, s_pts, s_nrm, d_dist, cpu_clustering, use_l1_norm,
                           use_averaged_clusters, allow_no_votes=True)
     return T, buf
+
+
+def register_database_by_model(models, scene, device):
+    """The other way to use several GPUs on a large model database (SURVEY 8e's alternative): the MODELS are
+    dealt to the ranks, every rank registers its share against the whole scene (ppf.Database: one scene pass
+    per d_dist group) and only the 4x4 poses travel.  `models`: this rank's ppf.Model objects, model j of the
+    database living on rank j % world; `scene`: unsharded.  Returns poses [n_total, 4, 4] on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    db = ppf.Database(models)
+    T, _ = db.align(scene)
+    db.close()
+    n_max = torch.tensor([len(models)], dtype=torch.int64, device=device)
+    dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+    block = int(n_max.item())
+    send = torch.zeros(block * 17, dtype=torch.float32, device=device)
+    if len(models):
+        flat = np.concatenate([np.ones((len(models), 1), np.float32), T.reshape(len(models), 16)], axis=1)
+        send[: flat.size] = torch.from_numpy(flat.reshape(-1)).to(device)
+    recv = torch.zeros(world * block * 17, dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    rec = recv.cpu().numpy().reshape(world, block, 17)
+    out = []
+    for k in range(block):                       # model j = k * world + r lives on rank r as its k-th
+        for r in range(world):
+            if rec[r, k, 0] == 1.0:
+                out.append(rec[r, k, 1:].reshape(4, 4))
+    return np.array(out, np.float32)
