@@ -329,3 +329,36 @@ def test_model_database_shares_the_scene_pass(ppf, oracle, built_lib, synth):
     for j, mo in enumerate(models):                             # members are whole again
         assert np.array_equal(mo.ppf_lookup(sc, allow_no_votes=True), single[j][0]), j
         assert cells_equal(mo.last_cells()[0], single[j][1])
+
+
+def test_align_multi_on_a_communicator_of_one(ppf, oracle, built_lib, case_small, case_two_slices):
+    """oslam_align_multi through RCCL with a world of one rank (all this box has): the all-reduce of the maximum, the
+    device-side filter with the global threshold, the all-gather with exact sizes and the pose tail on the union
+    give the single-GPU registration -- cells, counters and pose -- with the host tail and with the device tail."""
+    import os
+    comm = ppf.Comm(ppf.Comm.unique_id(), 0, 1, 0)
+    try:
+        for c, df in ((case_small, 1), (case_two_slices, 10)):
+            for tail_min in ("2", "1000000"):
+                os.environ["OSLAM_POSE_GPU_MIN"] = tail_min
+                mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+                sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=df)
+                T1 = mo.ppf_lookup(sc).copy()
+                cells1, st1 = mo.last_cells()[0], dict(mo.stats)
+                Tm = mo.align_multi(sc, comm)
+                assert np.array_equal(Tm, T1) and cells_equal(mo.last_cells()[0], cells1)
+                for k in ("num_votes", "num_hits", "max_count", "num_top"):
+                    assert mo.stats[k] == st1[k], k
+                ocells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], df, c["d"], 0.4)
+                assert cells_equal(cells1, ocells)
+                mo.close()
+    finally:
+        os.environ.pop("OSLAM_POSE_GPU_MIN", None)
+        comm.close()
+    # a scene whose shard is not the communicator's rank is refused
+    par = ppf.default_params(shard_rank=1, shard_world=2)
+    comm = ppf.Comm(ppf.Comm.unique_id(), 0, 1, 0)
+    mo = ppf.Model(case_small["mp"], case_small["mn"], d_dist=case_small["d"])
+    with pytest.raises(ppf.OslamError):
+        mo.align_multi(ppf.Scene(case_small["sp"], case_small["sn"], d_dist=case_small["d"], params=par), comm)
+    comm.close()
