@@ -456,8 +456,9 @@ struct VoteStep {
 /* An item whose every vote is re-evaluated with the reference's float sequence -- its bucket holds an
  * entry with the marker, or one of its hits carries it (degenerate geometry: a second point on the
  * reference point's normal, a non-finite coordinate): every (entry, hit) pair goes through the queue.
- * Rare and slow on purpose; called after the vote loop, never from inside it. */
-__device__ __noinline__ uint32_t forced_item(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n, uint32_t st,
+ * Rare and slow on purpose; used after the vote loop, never inside it (inlined there: a call anywhere in the
+ * kernel costs callee-saved registers and spills). */
+__device__ __forceinline__ uint32_t forced_item(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n, uint32_t st,
                                              uint32_t ln, uint32_t h0, uint32_t R, int lane)
 {
     for (uint32_t e = 0; e < ln; e += WAVE) {
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     __shared__ __attribute__((aligned(16))) uint32_t acc[ACC_CELLS + ACC_TRASH_WORDS];
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
-    __shared__ unsigned long long s_wave64[VOTE_THREADS / WAVE];
+    __shared__ unsigned long long s_tot[2];            /* votes; entries streamed | items << 40 */
     __shared__ uint32_t s_g, s_lmax, s_base, s_qn, s_next;
     __shared__ uint32_t s_tbl[32];
     __shared__ uint32_t s_q[VOTE_QCAP];
@@ -920,7 +921,6 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     for (int c = tid; c < ACC_CELLS / 4; c += VOTE_THREADS) reinterpret_cast<uint4 *>(acc)[c] = make_uint4(0, 0, 0, 0);
     if (tid < 32) s_tbl[tid] = k_alpha_thr[tid];
 
-    unsigned long long my_votes = 0, my_entries = 0;
     unsigned long long *sq = s_slow + (MODE == 0 ? wid * SLOW_CAP : 0);   /* this wave's re-evaluation queue */
     uint32_t sq_n = 0;
 #ifdef VOTE_PROF
@@ -933,21 +933,29 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         if (tid == 0) {
             s_qn = 0;
             s_next = 0;
+            if (first) s_tot[0] = s_tot[1] = 0;
         }
         __syncthreads();
         for (uint32_t k0 = 0; k0 < n_runs; k0 += VOTE_THREADS) {
             const uint32_t k = k0 + (uint32_t)tid;
             bool giant = false;
+            unsigned long long lv = 0, le = 0;
             if (k < n_runs) {
                 const oslamk_run rr = runs[k];
                 const uint32_t lf = uinfo[rr.slot_r & RUN_SLOT_MASK].len;
                 const uint32_t ln = lf & 0x7fffffffu, R = (rr.slot_r >> OSLAMK_RUN_SHIFT) + 1u;
-                if (first) {
-                    my_votes += (unsigned long long)ln * R;
-                    my_entries += ((unsigned long long)(ln != 0u) << 40) + ln;       /* items in the upper bits: one reduction for both */
-                }
+                lv = (unsigned long long)ln * R;
+                le = ((unsigned long long)(ln != 0u) << 40) + ln;       /* items in the upper bits: one reduction for both */
                 /* items with a marker (MODE 0) are neither giants nor small items: they wait for the pass after the loop */
                 giant = ((ln + 255u) >> 8) * R > T && !(MODE == 0 && ((lf | rr.first) >> 31));
+            }
+            if (first) {            /* summed over the wave and parked in LDS: no register lives on through the vote loops */
+                lv = wave_sum_u64(lv);
+                le = wave_sum_u64(le);
+                if (lane == 0 && le) {
+                    atomicAdd(&s_tot[0], lv);
+                    atomicAdd(&s_tot[1], le);
+                }
             }
             const unsigned long long gm = __ballot(giant);
             if (gm) {
@@ -967,15 +975,16 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     T = uni_u32(T);
 
     /* ---- the work of this wave, as windows of up to 64 step descriptors made lane-parallel ----
-     * A set of items sits one per lane: bucket start, length, first hit, hits, and the number of units the
-     * item is cut into (chunks, times 1, 2 or 4 ranges of hits for a giant).  The wave takes the units
-     * u0, u0 + stride, ... of the set: lane i of a window looks its unit up in the running sums of the set
-     * (binary search across lanes with ds_bpermute) and computes the step {first entry, entries left,
+     * A set of items sits in the lanes of two register pairs: the run record {slot | hits - 1, first hit} and
+     * the bucket record {start, length} of up to 64 items; `take` says which lanes belong to the set, and
+     * every item is cut into units (chunks, times 1, 2 or 4 ranges of hits for a giant).  The wave takes the
+     * units u0, u0 + stride, ... of the set: lane i of a window looks its unit up in the running sums of the
+     * set (binary search across lanes with ds_bpermute) and computes the step {first entry, entries left,
      * first hit, hits, hit range} -- about one instruction per step instead of a scalar generator of ~60.
      * The steps of a window are then voted in groups of VOTE_GROUP: descriptors to scalar registers,
      * all the group's loads back to back (16 B per lane each), the votes, one copy of the vote loop
      * per member so that each waits for its own registers only. */
-    uint32_t I_st = 0, I_ln = 0, I_h0 = 0, I_misc = 0, I_nu = 0, I_incl = 0;      /* the set: one item per lane */
+    uint2 B_ru = make_uint2(0, 0), B_inf = make_uint2(0, 0);
     auto bperm = [&](uint32_t from_lane, uint32_t v) -> uint32_t {
         return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
     };
@@ -993,14 +1002,21 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         d.valid = true;
         return d;
     };
-    /* votes the units u0, u0 + stride, ... < total of the current set */
-    auto vote_set = [&](uint32_t u0, uint32_t stride) {
-        uint32_t incl = I_nu;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += up;
+    /* hit ranges a chunk of an item with R hits is cut into, as a shift: giants only */
+    auto split_of = [&](uint32_t R, bool split) -> uint32_t { return !split ? 0u : R > 32u ? 2u : R > 16u ? 1u : 0u; };
+    /* votes the units u0, u0 + stride, ... of the items in the lanes where `take` holds */
+    auto vote_set = [&](bool take, bool split, uint32_t u0, uint32_t stride) {
+        uint32_t excl, incl;
+        {
+            const uint32_t R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+            const uint32_t nu = take ? (((B_inf.y & 0x7fffffffu) + 255u) >> 8) << split_of(R, split) : 0u;
+            incl = nu;
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, WAVE);
+                if (lane >= o) incl += up;
+            }
+            excl = incl - nu;
         }
-        I_incl = incl;
         const uint32_t total = readlane_u(incl, WAVE - 1);
         for (uint32_t ub = u0; ub < total; ub += stride * WAVE) {
             /* ---- the window: lane i <-> unit ub + stride * i ---- */
@@ -1008,11 +1024,11 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             const bool act = u < total;
             uint32_t lo = 0;                                   /* items whose running sum is <= u: the unit's item */
 #pragma unroll
-            for (uint32_t s2 = WAVE / 2; s2 > 0; s2 >>= 1) lo += bperm(lo + s2 - 1u, I_incl) <= u ? s2 : 0u;
+            for (uint32_t s2 = WAVE / 2; s2 > 0; s2 >>= 1) lo += bperm(lo + s2 - 1u, incl) <= u ? s2 : 0u;
             lo = lo < (uint32_t)WAVE - 1u ? lo : (uint32_t)WAVE - 1u;
-            const uint32_t st = bperm(lo, I_st), ln = bperm(lo, I_ln), h0 = bperm(lo, I_h0), mi = bperm(lo, I_misc);
-            const uint32_t local = u - (bperm(lo, I_incl) - bperm(lo, I_nu));
-            const uint32_t R = (mi & 63u) + 1u, lg = mi >> 6;
+            const uint32_t st = bperm(lo, B_inf.x), ln = bperm(lo, B_inf.y) & 0x7fffffffu, h0 = bperm(lo, B_ru.y) & 0x7fffffffu;
+            const uint32_t R = (bperm(lo, B_ru.x) >> OSLAMK_RUN_SHIFT) + 1u, lg = split_of(R, split);
+            const uint32_t local = u - bperm(lo, excl);
             const uint32_t c = local >> lg, hs = local & ((1u << lg) - 1u), per = (R + (1u << lg) - 1u) >> lg;
             const uint32_t i0 = hs * per, i1 = i0 + per < R ? i0 + per : R;
             /* a lane past the end describes a step that loads entry 0 and hit 0 and votes nothing */
@@ -1033,89 +1049,89 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
             }
         }
     };
-    /* item of a lane from its run and bucket records; units = chunks << lg (0 = not voted here) */
-    auto set_item = [&](const uint2 &ru, const uint2 &inf, bool take, uint32_t lg) {
-        const uint32_t ln = inf.y & 0x7fffffffu, R = (ru.x >> OSLAMK_RUN_SHIFT) + 1u;
-        I_st = inf.x;
-        I_ln = ln;
-        I_h0 = ru.y & 0x7fffffffu;
-        I_misc = (R - 1u) | (lg << 6);
-        I_nu = take ? ((ln + 255u) >> 8) << lg : 0u;
-    };
     auto marked = [&](const uint2 &ru, const uint2 &inf) -> bool { return MODE == 0 && ((inf.y | ru.y) >> 31); };
 
     /* ---- the sets, one after the other (one call site of vote_set: its vote loops exist once) ----
      * giants first: 64 queued items at a time, their units dealt round-robin to the waves;
-     * then the rest, dynamically: VOTE_BLOCK runs at a time from a counter in LDS; the run records of the
-     * block two ahead and the bucket records of the next one are in flight */
+     * then the rest, dynamically: VOTE_BLOCK runs at a time from a counter in LDS.  Four blocks sit side by
+     * side in the lanes of B_ru / B_inf (block b in lanes 16 * (b's turn mod 4) ..): the one being voted, the
+     * next (its bucket records in flight) and the one after it (its run records in flight) */
     {
         const uint32_t n_blocks = (n_runs + VOTE_BLOCK - 1) / VOTE_BLOCK;
+        const uint32_t my_slot = (uint32_t)lane / VOTE_BLOCK, k_in = (uint32_t)lane % VOTE_BLOCK;
         auto grab = [&]() -> uint32_t {
             uint32_t b = 0;
             if (lane == 0) b = atomicAdd(&s_next, 1u);
             return uni_u32(readlane_u(b, 0));
         };
-        auto fetch_runs = [&](uint32_t b) -> uint2 {
-            const uint32_t k = b * VOTE_BLOCK + (uint32_t)lane;
-            uint2 ru = make_uint2(0, 0);
-            if (lane < VOTE_BLOCK && k < n_runs) {
-                const oslamk_run rr = runs[k];
-                ru = make_uint2(rr.slot_r, rr.first);
+        /* run records of block b into the lanes of `slot` (zeros past the end of the run list) */
+        auto fetch_runs = [&](uint32_t b, uint32_t slot) {
+            if (my_slot == slot) {
+                const uint32_t k = b * VOTE_BLOCK + k_in;
+                B_ru = make_uint2(0, 0);
+                B_inf = make_uint2(0, 0);
+                if (k < n_runs) {
+                    const oslamk_run rr = runs[k];
+                    B_ru = make_uint2(rr.slot_r, rr.first);
+                }
             }
-            return ru;
         };
-        auto fetch_info = [&](uint32_t b, const uint2 &ru) -> uint2 {
-            const uint32_t k = b * VOTE_BLOCK + (uint32_t)lane;
-            uint2 inf = make_uint2(0, 0);
-            if (lane < VOTE_BLOCK && k < n_runs) {
-                const oslamk_uinfo ui = uinfo[ru.x & RUN_SLOT_MASK];
-                inf = make_uint2(ui.start, ui.len);
+        /* bucket records of the block in `slot` (its run records have landed) */
+        auto fetch_info = [&](uint32_t b, uint32_t slot) {
+            if (my_slot == slot && b * VOTE_BLOCK + k_in < n_runs) {
+                const oslamk_uinfo ui = uinfo[B_ru.x & RUN_SLOT_MASK];
+                B_inf = make_uint2(ui.start, ui.len);
             }
-            return inf;
         };
-        uint32_t cur_b = grab();
-        uint2 cur_ru = fetch_runs(cur_b);
-        uint32_t nx1_b = grab();
-        uint2 nx1_ru = fetch_runs(nx1_b);
-        uint32_t nx2_b = grab();
-        uint2 nx2_ru = fetch_runs(nx2_b);
-        uint2 cur_inf = fetch_info(cur_b, cur_ru);
-        uint2 nx1_inf = fetch_info(nx1_b, nx1_ru);
+        uint32_t cur_b = 0, nx1_b = 0, nx2_b = 0, turn = 0;
         uint32_t tw = 0;                                 /* giants: first queue entry of the next set */
+        bool started = false;
         for (;;) {
+            bool take, split;
             uint32_t u0, stride;
             if (tw < n_q) {
                 const uint32_t t = tw + (uint32_t)lane;
-                uint2 ru = make_uint2(0, 0), inf = make_uint2(0, 0);
+                B_ru = make_uint2(0, 0);
+                B_inf = make_uint2(0, 0);
                 if (t < n_q) {
                     const oslamk_run rr = runs[s_q[t]];
                     const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
-                    ru = make_uint2(rr.slot_r, rr.first);
-                    inf = make_uint2(ui.start, ui.len);
+                    B_ru = make_uint2(rr.slot_r, rr.first);
+                    B_inf = make_uint2(ui.start, ui.len);
                 }
-                const uint32_t R = (ru.x >> OSLAMK_RUN_SHIFT) + 1u;
-                set_item(ru, inf, t < n_q, R > 32u ? 2u : R > 16u ? 1u : 0u);      /* the hits of a chunk in 1, 2 or 4 units */
                 tw += WAVE;
+                take = t < n_q;
+                split = true;
                 u0 = uni_u32((uint32_t)wid);
                 stride = VOTE_THREADS / WAVE;
             } else {
+                if (!started) {                          /* the first three blocks of this wave */
+                    started = true;
+                    cur_b = grab();
+                    fetch_runs(cur_b, 0u);
+                    nx1_b = grab();
+                    fetch_runs(nx1_b, 1u);
+                    nx2_b = grab();
+                    fetch_runs(nx2_b, 2u);
+                    fetch_info(cur_b, 0u);
+                    fetch_info(nx1_b, 1u);
+                }
                 if (cur_b >= n_blocks) break;            /* the counter only grows: this wave is done */
-                const uint32_t ln = cur_inf.y & 0x7fffffffu, R = (cur_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
-                /* present in the slice, not a giant (those are done), no marker (those come last) */
-                set_item(cur_ru, cur_inf, ln != 0u && ((ln + 255u) >> 8) * R <= T && !marked(cur_ru, cur_inf), 0u);
-                /* the next blocks move up before the votes, so that their loads fly meanwhile */
-                cur_ru = nx1_ru;
-                cur_inf = nx1_inf;
-                cur_b = nx1_b;
-                nx1_ru = nx2_ru;
-                nx1_b = nx2_b;
-                nx1_inf = fetch_info(nx1_b, nx1_ru);
-                nx2_b = grab();
-                nx2_ru = fetch_runs(nx2_b);
+                const uint32_t ln = B_inf.y & 0x7fffffffu, R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+                /* of the current block: present in the slice, not a giant (those are done), no marker (those come last) */
+                take = my_slot == (turn & 3u) && ln != 0u && ((ln + 255u) >> 8) * R <= T && !marked(B_ru, B_inf);
+                split = false;
                 u0 = 0u;
                 stride = 1u;
+                /* the next blocks move up before the votes, so that their loads fly meanwhile */
+                cur_b = nx1_b;
+                nx1_b = nx2_b;
+                fetch_info(nx1_b, (turn + 2u) & 3u);
+                nx2_b = grab();
+                fetch_runs(nx2_b, (turn + 3u) & 3u);
+                turn++;
             }
-            vote_set(u0, stride);
+            vote_set(take, split, u0, stride);
         }
     }
     if (MODE == 0) {
@@ -1163,16 +1179,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     }
     lmax = wave_max_u32(lmax);
     nz = wave_sum_u32(nz);
-    my_votes = wave_sum_u64(my_votes);
-    my_entries = wave_sum_u64(my_entries);
     if (lane == 0) {
         s_wave[wid] = lmax;
         s_wave2[wid] = nz;
-        s_wave64[wid] = my_votes;
-        if (my_entries) {
-            atomicAdd(&a.counters->entries, my_entries & 0xffffffffffull);
-            atomicAdd(&a.counters->items, my_entries >> 40);
-        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1182,7 +1191,11 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
             m = s_wave[w] > m ? s_wave[w] : m;
             n += s_wave2[w];
-            v += s_wave64[w];
+        }
+        v = s_tot[0];
+        if (s_tot[1]) {
+            atomicAdd(&a.counters->entries, s_tot[1] & 0xffffffffffull);
+            atomicAdd(&a.counters->items, s_tot[1] >> 40);
         }
         uint32_t g = a.fixed_gmax;
         if (g == 0) {
