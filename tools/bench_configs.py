@@ -60,6 +60,29 @@ def cfg3():
             "instances_found": {mid: found_at_reference_criterion(res[mid][0], T, clouds[mid][0]) for mid, T in poses}}
 
 
+def cfg3db():
+    """cfg3 through the database object, once with every model's own d_dist (ten groups of one) and once with ONE
+    d_dist for the whole database (one group: one scene pass per frame for all ten models)."""
+    ids = list(range(10))
+    clouds = [synth.make_model(k, 5000) for k in ids]
+    dd = [synth.d_dist_for(c[0], 0.025) for c in clouds]
+    sp, sn, poses = synth.make_scene([0, 4, 8], 100000, 2003, instance_points=5000, noise_sigma=0.1 * dd[0])
+    sc = ppf.Scene(sp, sn, d_dist=0.0, ref_point_downsample_factor=10)
+    out = {"config": "cfg3 through oslam_db: 10-model database vs 100k scene", "ref_point_df": 10}
+    for name, dds in (("own_d_dist", dd), ("common_d_dist", [dd[0]] * 10)):
+        models = [ppf.Model(c[0], c[1], d_dist=d) for c, d in zip(clouds, dds)]
+        db = ppf.Database(models)
+        db.align(sc)
+        t = time.perf_counter(); T, stats = db.align(sc); el = time.perf_counter() - t
+        out[name] = {"groups": db.n_groups, "frame_s": el, "votes_per_s": sum(s["num_votes"] for s in stats) / el,
+                     "key_kernels_ms": sum(s["ms_key_kernel"] for s in stats), "vote_kernels_ms": sum(s["ms_vote_kernel"] for s in stats),
+                     "instances_found": {mid: found_at_reference_criterion(T[mid], Tt, clouds[mid][0]) for mid, Tt in poses}}
+        db.close()
+        for m in models:
+            m.close()
+    return out
+
+
 def cfg4(n_models=4):
     ids = list(range(n_models))
     clouds = [synth.make_model(k, 5000) for k in ids]
@@ -124,4 +147,4 @@ def cfg5(n_models=4, frames=8):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-    print(json.dumps({"cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[which]()), flush=True)
+    print(json.dumps({"cfg2": cfg2, "cfg3": cfg3, "cfg3db": cfg3db, "cfg4": cfg4, "cfg5": cfg5}[which]()), flush=True)
