@@ -110,7 +110,22 @@ def main():
     t_build = time.time() - t0
     scene = ppf.Scene(sp, sn, d_dist=d_dist, ref_point_downsample_factor=df, params=par)   # resident in HBM
     model.prepare(scene)      # per-device counters and pose-tail tables: set-up, like the model table itself
-    comm = pkg.dist.make_comm(dev_index) if (world > 1 and backend == "nccl") else None
+    # N > 1 over RCCL: the exchange runs inside the library (oslam_align_multi).  If its communicator cannot be made on
+    # this node the same steps run through host buffers and torch.distributed instead -- on every rank or on none
+    comm, exchange = None, "single GPU"
+    if world > 1 and backend == "nccl":
+        try:
+            comm = pkg.dist.make_comm(dev_index)
+        except Exception as e:                       # noqa: BLE001 -- reported below, the run goes on
+            log("[rank %d] oslam_comm_create failed (%s): exchange through host buffers" % (rank, e))
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=xdev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+        exchange = "oslam_align_multi (RCCL inside the library)" if comm is not None else "host buffers + torch.distributed (nccl)"
+    elif world > 1:
+        exchange = "host buffers + torch.distributed (%s)" % backend
     log("[rank %d] model build %.3fs, d_dist %.5f, df %d" % (rank, t_build, d_dist, df))
 
     def step(sc=scene):
@@ -217,7 +232,7 @@ def main():
                        "model_points": M, "scene_points": S, "tau_d": args.tau_d, "d_dist": d_dist,
                        "ref_point_df": df, "ref_points_per_gpu": int(st["num_scene_ppfs"] // (S - 1)),
                        "vote_mode": args.vote_mode, "vote_count_threshold": 0.4,
-                       "parallelism": "scene-ref-shard x%d" % world},
+                       "parallelism": "scene-ref-shard x%d" % world, "exchange": exchange},
             "vote_increments_per_sec": total_votes / elapsed,
             "hits_per_sec": total_hits / elapsed,
             "ms_per_step_incl_scene": ms_incl,
