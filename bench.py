@@ -187,7 +187,7 @@ def main():
 
     if rank == 0:
         st = stats_acc[-1]
-        n_slices = (M + 1022) // 1023
+        n_slices = (M + 2045) // 2046
         launches = sum(s["vote_launches"] for s in stats_acc)
         ms_vote_kernel = float(sum(s["ms_vote_kernel"] for s in stats_acc))   # HIP events around each launch
         ms_key_kernel = float(sum(s["ms_key_kernel"] for s in stats_acc))

@@ -73,7 +73,8 @@ typedef struct oslam_stats {
     uint32_t vote_launches;        /* launches of the vote kernel (one per batch of reference points) */
     float ms_vote_kernel;          /* sum over the vote-kernel launches alone (HIP events around each) */
     float ms_key_kernel;           /* sum over the scene-key and hit-sort kernel launches */
-    uint32_t reserved0;
+    uint32_t wide_workgroups;      /* vote workgroups (reference point x table slice) whose 16-bit counters overflowed and
+                                    * were voted again with 32-bit counters (0 unless both clouds hold large planes) */
     uint64_t num_pairs_probed;     /* of num_scene_ppfs, the pairs whose distance bin can reach a model key: they are keyed
                                     * and probed; the others cannot hit and are dropped by the distance test alone */
     uint64_t scratch_bytes;        /* size of the device's hit-list pool after this call */
@@ -286,8 +287,9 @@ int oslam_model_keys(oslam_model *m, size_t ref_index, uint32_t *keys_out);
  * bucket size in *count_out and copies at most cap indices. */
 int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t cap,
                        size_t *count_out);
-/* The stored words theta_u << 10 | (m_r - 1023*slice) of one key's bucket in one table slice (slices hold
- * 1023 model reference points), in storage order (what a vote wave streams, 4 consecutive words per lane). */
+/* The stored words theta_u << 11 | half << 10 | row of one key's bucket in one table slice (slices hold 2 x 1023
+ * model reference points: m_r - 2046*slice = 1023*half + row), in storage order (what a vote wave streams, 4
+ * consecutive words per lane). */
 int oslam_model_bucket_words(oslam_model *m, uint32_t key, int slice, uint32_t *words_out, size_t cap,
                              size_t *count_out);
 /* Dense accumulator acc[M][32] of scene reference point ref_index after voting. */

@@ -513,8 +513,8 @@ done:
 static int build_uinfo(oslam_model *m);
 
 #define OSLAM_DB_MAGIC 0x4c444d4f534c4f00ull     /* "\0OLSOMDL" */
-#define OSLAM_DB_VERSION 5u                      /* table layout: 16-B slots, slices of 1023 points, e4 = theta (2^-22 turn) << 10 | row, padding
-                                                  * words = row 1023; checksum covers the header */
+#define OSLAM_DB_VERSION 6u                      /* table layout: 16-B slots, slices of 2046 points, e4 = theta (2^-21 turn) << 11 | half << 10 | row,
+                                                  * padding words = row 1023; checksum covers the header */
 typedef struct db_header {
     uint64_t magic;
     uint32_t version, vote_mode;
@@ -925,6 +925,8 @@ typedef struct {
     int have_events;
     char *d_cluster;                   /* workspace of cluster_scores_on_device */
     size_t cluster_bytes;
+    uint32_t *d_redo;                  /* vote workgroups of a batch whose 16-bit counters overflowed */
+    size_t redo_cap;
 } scratch_pool;
 static scratch_pool g_pool[MAX_DEVICES];
 static pthread_once_t g_pool_once = PTHREAD_ONCE_INIT;
@@ -954,11 +956,12 @@ int oslam_release_scratch(int dev)
     scratch_pool *p = pool_lock(dev);
     int i;
     if (!p) return fail(OSLAM_E_INVALID, "device ordinal out of range");
-    if (p->buf || p->d_counts || p->have_events || p->d_cluster) {
+    if (p->buf || p->d_counts || p->have_events || p->d_cluster || p->d_redo) {
         if (hipSetDevice(dev) != hipSuccess) { pool_unlock(p); return fail(OSLAM_E_DEVICE, "hipSetDevice failed"); }
         if (p->buf) (void)hipFree(p->buf);
         if (p->d_counts) (void)hipFree(p->d_counts);
         if (p->d_cluster) (void)hipFree(p->d_cluster);
+        if (p->d_redo) (void)hipFree(p->d_redo);
         oslamk_pose_release();
         if (p->have_events)
             for (i = 0; i < 4 + 3 * MAX_BATCH_EVENTS; i++) (void)hipEventDestroy(p->ev[i]);
@@ -972,6 +975,8 @@ int oslam_release_scratch(int dev)
     p->have_events = 0;
     p->d_cluster = NULL;
     p->cluster_bytes = 0;
+    p->d_redo = NULL;
+    p->redo_cap = 0;
     pool_unlock(p);
     return OSLAM_OK;
 }
@@ -1031,6 +1036,7 @@ static int pool_reserve_slots(scratch_pool *p, size_t slots)
 static void carve_scratch(oslamk_vote_args *a, const scratch_pool *p, size_t slots)
 {
     char *b = p->buf;
+    a->redo = p->d_redo;
     a->hit_pay = (oslamk_pay *)b;
     b += slots * sizeof(oslamk_pay);
     a->hit_sorted = (oslamk_pay *)b;
@@ -1081,6 +1087,17 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
     float k0 = 0.0f;
     rc = pool_reserve_counts(pool, (size_t)(n_ref > 0 ? n_ref : 1));
     if (rc != OSLAM_OK) return rc;
+    {
+        /* one place per vote workgroup of the largest launch: (reference points padded to 8) x slices */
+        size_t nsl = 1, need;
+        for (j = 0; j < nm; j++) if ((size_t)ms[j]->table.n_slices > nsl) nsl = (size_t)ms[j]->table.n_slices;
+        need = (((size_t)(n_ref > 0 ? n_ref : 1) + 7) / 8 * 8) * nsl;
+        if (pool->redo_cap < need) {
+            if (pool->d_redo) { (void)hipFree(pool->d_redo); pool->d_redo = NULL; pool->redo_cap = 0; }
+            HIPCHK(hipMalloc((void **)&pool->d_redo, sizeof(uint32_t) * (need + need / 4)));
+            pool->redo_cap = need + need / 4;
+        }
+    }
     ev = pool->ev;
     cap = pool->counts_cap;
     d_keep = pool->d_counts;
@@ -1171,6 +1188,8 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
                 a.out_cap = mj->out_cap;
                 a.mode = (mj->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
                 KCHK(oslamk_vote(&a, g_stream));
+                /* the redo list belongs to this launch */
+                HIPCHK(hipMemsetAsync(&mj->d_counters->redo_count, 0, sizeof(uint32_t), st));
             }
             if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb + 2], st));
             if (launches) *launches += 1;
@@ -1296,6 +1315,7 @@ static int vote_and_fetch(scratch_pool *pool, oslam_model *m, oslam_scene *s, os
         st->num_pairs_probed = probed;
         st->num_entries_streamed = cnt->entries;
         st->num_items = cnt->items;
+        st->wide_workgroups = cnt->redo_total;
         st->scratch_bytes = pool->bytes;
     }
 done:
@@ -1997,6 +2017,7 @@ int oslam_db_align(oslam_db *db, oslam_scene *s, float *T_out, oslam_stats *stat
                 st->scratch_bytes = pool->bytes;
                 st->num_entries_streamed = cnt[k].entries;
                 st->num_items = cnt[k].items;
+                st->wide_workgroups = cnt[k].redo_total;
                 if (n && !(pose_gpu_from(m) && n >= pose_gpu_from(m)))
                     HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * n, hipMemcpyDeviceToHost));
                 arc = OSLAM_OK;
@@ -2138,7 +2159,7 @@ int oslam_model_bucket(oslam_model *m, uint32_t key, uint32_t *pairs_out, size_t
                 HIPCHK(hipMemcpy(tmi, m->ent.mi + tab[slot].start, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
                 for (e = 0; e < len; e++, total++)
                     if (pairs_out && written < cap)
-                        pairs_out[written++] = ((uint32_t)s * OSLAMK_SLICE + (tmp[e] & PC_ROW_MASK)) * (uint32_t)m->c.n + tmi[e];
+                        pairs_out[written++] = ((uint32_t)s * OSLAMK_SLICE + pc_local_of_row11(tmp[e] & PC_ROW_MASK)) * (uint32_t)m->c.n + tmi[e];
                 break;
             }
             if (tab[slot].key == 0) break;

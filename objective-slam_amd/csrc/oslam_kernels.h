@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-#define OSLAMK_SLICE 1023      /* model reference points per table slice */
+#define OSLAMK_SLICE 2046      /* model reference points per table slice: two per 32-bit counter word of a row (ppf_core.h) */
 #define OSLAMK_ROWS 1024       /* rows of the LDS accumulator: one per reference point of the slice + the sink row of padding entries */
 #define OSLAMK_NBIN 32         /* alpha bins per accumulator row (reference uses 0..30) */
 
@@ -28,9 +28,10 @@ typedef struct oslamk_slot {
 
 /* Model pair entries, bucketed by (slice, key); every bucket starts on a multiple of 4
  * entries so that a lane can fetch 4 of them with one 16-byte load.
- *   e4[e] = theta_u << 10 | (m_r - slice*OSLAMK_SLICE)   the 4 bytes a vote streams (pc_entry_word;
- *           theta_u = pc_angle_t22 of (T_m_g * m_i).y/.z, kernel.cu:330-332); the up to 3 padding
- *           words behind a bucket hold row 1023, the accumulator's sink row
+ *   e4[e] = theta_u << 11 | half << 10 | row   the 4 bytes a vote streams (pc_entry_word; theta_u =
+ *           pc_angle_t22 of (T_m_g * m_i).y/.z, kernel.cu:330-332, in units of 2^-21 turn; half, row =
+ *           pc_row11(m_r - slice*OSLAMK_SLICE)); the up to 3 padding words behind a bucket hold row
+ *           1023, the accumulator's sink row
  *   uv[e] = (T_m_g * m_i).y/.z as floats: read only by the rare votes that are
  *           re-evaluated with the reference's own arithmetic (exact mode)
  *   mi[e] = m_i (parity tap only) */
@@ -80,7 +81,8 @@ typedef struct oslamk_counters {
     unsigned long long nonzero_cells;
     uint32_t gmax;
     uint32_t out_count;
-    uint32_t pad[2];
+    uint32_t redo_count;          /* vote workgroups of the current launch whose 16-bit counters overflowed (redo list length) */
+    uint32_t redo_total;          /* the same, summed over the launches of a call */
     unsigned long long entries;   /* model pair entries streamed: sum of the bucket lengths over (run, slice) */
     unsigned long long items;     /* (run, slice) pairs with a bucket */
     unsigned long long prof[4];   /* -DVOTE_PROF builds: k_vote wave cycles (end of voting, barrier, peak extraction, vote steps) */
@@ -162,6 +164,7 @@ typedef struct oslamk_vote_args {
     oslamk_run *runs;
     uint32_t *hit_count;       /* [n_launch] */
     uint32_t *run_count;       /* [n_launch] */
+    uint32_t *redo;            /* [vote workgroups of the batch] list of those whose 16-bit counters overflowed */
 } oslamk_vote_args;
 
 /* fill t.uinfo from the slice tables (after oslamk_table_scan / oslamk_union_build and the fill pass) */

@@ -41,7 +41,7 @@
 #define WAVE 64
 #define VOTE_THREADS 1024
 #define ACC_CELLS (OSLAMK_ROWS * OSLAMK_NBIN)
-#define ACC_REAL_CELLS (OSLAMK_SLICE * OSLAMK_NBIN)      /* without the sink row */
+#define ACC_REAL_CELLS (1023 * OSLAMK_NBIN)      /* counter words without the sink row; each holds two 16-bit counters */
 
 /* thresholds of pc_alpha_bin_table(); every vote workgroup copies them into LDS */
 __device__ const uint32_t k_alpha_thr[32] = {PC_ALPHA_THR_FLAT};
@@ -235,7 +235,7 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
         const uint32_t th = pc_angle_t22(uy, uz);
         /* a marker forces the whole bucket through the exact path: flagged in bit 31 of the cursor */
         if (th == PC_T22_FORCE) atomicOr(&tab[slot].cur, 0x80000000u);
-        ent.e4[e] = pc_entry_word(th == PC_T22_FORCE ? 0u : th, (uint32_t)(m_r - slice * OSLAMK_SLICE));
+        ent.e4[e] = pc_entry_word(th == PC_T22_FORCE ? 0u : th, pc_row11((uint32_t)(m_r - slice * OSLAMK_SLICE)));
     }
     ent.mi[e] = (uint16_t)i;
     if (ent.uv) {
@@ -398,12 +398,14 @@ struct SlowCtx {
     const oslamk_pay *hits;
     const float *px, *py, *pz;
     const float *rows;
+    uint32_t inc_lo, inc_hi;           /* what a vote adds to its counter word: by the half the model point owns */
+    uint32_t dropped;                  /* re-evaluated votes that fell into no bin (alpha not a number) */
 };
 
 /* LDS pointers of the out-of-line paths; their context lives in LDS too (a kernel's stack would be scratch memory) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-typedef __attribute__((address_space(3))) const SlowCtx lds_ctx;
+typedef __attribute__((address_space(3))) SlowCtx lds_ctx;
 
 /* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index, hit index};
  * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
@@ -417,14 +419,16 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
         if (base + lane < n) {
             const unsigned long long it = q[base + lane];
             const uint32_t entry = (uint32_t)it;
-            const uint32_t mr = sc->e4[entry] & PC_ROW_MASK;
+            const uint32_t ew = sc->e4[entry];
+            const uint32_t mr = ew & PC_ROW10_MASK;
             const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
             const uint32_t i = sc->hits[(uint32_t)(it >> 32)].idx;
             const float x = sc->px[i], y = sc->py[i], z = sc->pz[i];
             const float vy = pc_row_dot(sc->rows, x, y, z);        /* as k_scene_hits computed them */
             const float vz = pc_row_dot(sc->rows + 4, x, y, z);
             const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
-            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[(mr << 5) + bin], 1u);
+            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[(mr << 5) + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
+            else atomicAdd((uint32_t *)&sc->dropped, 1u);
         }
     }
 }
@@ -491,20 +495,26 @@ struct VoteRegs {
     }
     /* returns the length of the wave's re-evaluation queue */
     __device__ __forceinline__ uint32_t vote(const SlowCtx *scp, uint32_t *accp, const uint32_t *tblp, unsigned long long *qp,
-                                             uint32_t qn, const VoteStep &d, int lane) const
+                                             uint32_t qn, const VoteStep &d, int lane, uint32_t inc_lo, uint32_t inc_hi) const
     {
         lds_ctx *sc = (lds_ctx *)scp;
         lds_u32 *acc = (lds_u32 *)accp, *tbl = (lds_u32 *)tblp;
         lds_u64 *q = (lds_u64 *)qp;
-        /* the entry words as they are: theta_u << 10 | row (pc_entry_word); lanes and words past the end of
-         * the bucket are masked out of the atomics (EXEC) or are padding entries that vote into the sink row */
+        /* the entry words as they are: theta_u << 11 | half << 10 | row (pc_entry_word); lanes and words past the
+         * end of the bucket are masked out of the atomics (EXEC) or are padding entries that vote into the sink
+         * row.  A counter word holds two 16-bit counters: the model points of the lower half of the slice add 1,
+         * those of the upper half 0x10000 (inc_lo / inc_hi; one of them is 0 in the rare second and third pass
+         * of a workgroup whose 16-bit counters overflowed) */
         const uint32_t wa[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t32(th);
         const uint32_t acc_base = (uint32_t)(uintptr_t)acc;  /* the accumulator's LDS address */
         const uint32_t trash_addr = acc_base + 4u * (ACC_TRASH + (uint32_t)lane);
-        uint32_t rowb[4];
+        uint32_t rowb[4], inc[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) rowb[j] = acc_base + ((wa[j] & PC_ROW_MASK) << 7);     /* LDS address of the entry's row */
+        for (int j = 0; j < 4; j++) {
+            rowb[j] = acc_base + ((wa[j] & PC_ROW10_MASK) << 7);     /* LDS address of the entry's row */
+            inc[j] = (wa[j] >> PC_ROW_HALF_BIT) & 1u ? inc_hi : inc_lo;
+        }
         /* lanes that hold at least one entry of this chunk */
         const unsigned long long live = __ballot(4u * (uint32_t)lane < d.left);
 #ifdef VOTE_DIAG_NOLOOP                 /* timing-only build: steps and loads without the votes */
@@ -555,12 +565,13 @@ struct VoteRegs {
             asm volatile("s_mov_b64 %0, exec\n\t"
                          "s_mov_b64 exec, %1\n\t"
                          "ds_add_u32 %2, %6\n\t"
-                         "ds_add_u32 %3, %6\n\t"
-                         "ds_add_u32 %4, %6\n\t"
-                         "ds_add_u32 %5, %6\n\t"
+                         "ds_add_u32 %3, %7\n\t"
+                         "ds_add_u32 %4, %8\n\t"
+                         "ds_add_u32 %5, %9\n\t"
                          "s_mov_b64 exec, %0"
                          : "=&s"(saved)
-                         : "s"(live), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(1u)
+                         : "s"(live), "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(inc[0]), "v"(inc[1]),
+                           "v"(inc[2]), "v"(inc[3])
                          : "memory");
         }
         return qn;
@@ -878,13 +889,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 #endif
 #define RUN_SLOT_MASK ((1u << OSLAMK_RUN_SHIFT) - 1u)
 
-template <int MODE>
-__global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
+template <int MODE, int PASS>
+__device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint32_t wg)
 {
     __shared__ __attribute__((aligned(16))) uint32_t acc[ACC_CELLS + ACC_TRASH_WORDS];
     __shared__ uint32_t s_wave[VOTE_THREADS / WAVE];
     __shared__ uint32_t s_wave2[VOTE_THREADS / WAVE];
     __shared__ unsigned long long s_tot[2];            /* votes; entries streamed | items << 40 */
+    __shared__ unsigned long long s_sum[VOTE_THREADS / WAVE];
+    __shared__ uint32_t s_redo;
     __shared__ uint32_t s_g, s_lmax, s_base, s_qn, s_next;
     __shared__ uint32_t s_tbl[32];
     __shared__ uint32_t s_q[VOTE_QCAP];
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     typedef VoteRegs<MODE> VR;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const uint32_t nsl = (uint32_t)a.table.n_slices;
-    const uint32_t xg = blockIdx.x & 7u, xi = blockIdx.x >> 3;
+    const uint32_t xg = wg & 7u, xi = wg >> 3;
     const int ref_local = (int)((xi / nsl) * 8u + xg);
     const int slice = (int)(xi % nsl);
     if (ref_local >= a.n_launch) return;             /* the grid is padded to a multiple of 8 reference points */
@@ -915,6 +928,9 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
         s_ctx.py = a.scene.py;
         s_ctx.pz = a.scene.pz;
         s_ctx.rows = a.tsg + 8 * (size_t)ref_ord;
+        s_ctx.inc_lo = PASS == 2 ? 0u : 1u;
+        s_ctx.inc_hi = PASS == 0 ? 0x10000u : PASS == 2 ? 1u : 0u;
+        s_ctx.dropped = 0;
     }
     const SlowCtx *sc = &s_ctx;
 
@@ -974,291 +990,353 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
     const uint32_t n_q = uni_u32(s_qn);
     T = uni_u32(T);
 
-    /* ---- the work of this wave, as windows of up to 64 step descriptors made lane-parallel ----
-     * A set of items sits in the lanes of two register pairs: the run record {slot | hits - 1, first hit} and
-     * the bucket record {start, length} of up to 64 items; `take` says which lanes belong to the set, and
-     * every item is cut into units (chunks, times 1, 2 or 4 ranges of hits for a giant).  The wave takes the
-     * units u0, u0 + stride, ... of the set: lane i of a window looks its unit up in the running sums of the
-     * set (binary search across lanes with ds_bpermute) and computes the step {first entry, entries left,
-     * first hit, hits, hit range} -- about one instruction per step instead of a scalar generator of ~60.
-     * The steps of a window are then voted in groups of VOTE_GROUP: descriptors to scalar registers,
-     * all the group's loads back to back (16 B per lane each), the votes, one copy of the vote loop
-     * per member so that each waits for its own registers only. */
-    uint2 B_ru = make_uint2(0, 0), B_inf = make_uint2(0, 0);
-    auto bperm = [&](uint32_t from_lane, uint32_t v) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
-    };
-    /* step g of a window: its descriptor from lane g of the window's registers (VOTE_GROUP divides 64, so a
-     * group never runs past lane 63; lanes past the window's end describe empty steps) */
-    auto step_at = [&](uint32_t ve0, uint32_t vleft, uint32_t vh0, uint32_t vmisc, int l) -> VoteStep {
-        VoteStep d;
-        const uint32_t misc = readlane_u(vmisc, l);
-        d.e0 = readlane_u(ve0, l);
-        d.left = readlane_u(vleft, l);
-        d.h0 = readlane_u(vh0, l);
-        d.R = (misc & 63u) + 1u;
-        d.i0 = (misc >> 6) & 127u;
-        d.i1 = (misc >> 13) & 127u;
-        d.valid = true;
-        return d;
-    };
-    /* hit ranges a chunk of an item with R hits is cut into, as a shift: giants only */
-    auto split_of = [&](uint32_t R, bool split) -> uint32_t { return !split ? 0u : R > 32u ? 2u : R > 16u ? 1u : 0u; };
-    /* votes the units u0, u0 + stride, ... of the items in the lanes where `take` holds */
-    auto vote_set = [&](bool take, bool split, uint32_t u0, uint32_t stride) {
-        uint32_t excl, incl;
+    /* A counter word of the accumulator holds two 16-bit counters (two model reference points per row: a slice of
+     * 2046 fits the 128 KiB).  PASS 0 -- the kernel every registration runs -- votes into both at once.  A counter
+     * that passes 65535 carries into its neighbour: the sum of all counters then falls short of the votes cast
+     * (every overflow takes 65535 or 65536 away, never adds); the workgroup notices, emits nothing and puts itself
+     * on the redo list, and k_vote_wide votes for it again with full 32-bit counters, first for the lower half of
+     * the slice's model points (PASS 1), then for the upper (PASS 2).  Counts beyond 16 bits need large planar
+     * surfaces in both clouds; the bench scene's largest cell is 17 186. */
+    const uint32_t pass = PASS;
+    const uint32_t inc_lo = PASS == 2 ? 0u : 1u, inc_hi = PASS == 0 ? 0x10000u : PASS == 2 ? 1u : 0u;
+    {
+        /* ---- the work of this wave, as windows of up to 64 step descriptors made lane-parallel ----
+         * A set of items sits in the lanes of two register pairs: the run record {slot | hits - 1, first hit} and
+         * the bucket record {start, length} of up to 64 items; `take` says which lanes belong to the set, and
+         * every item is cut into units (chunks, times 1, 2 or 4 ranges of hits for a giant).  The wave takes the
+         * units u0, u0 + stride, ... of the set: lane i of a window looks its unit up in the running sums of the
+         * set (binary search across lanes with ds_bpermute) and computes the step {first entry, entries left,
+         * first hit, hits, hit range} -- about one instruction per step instead of a scalar generator of ~60.
+         * The steps of a window are then voted in groups of VOTE_GROUP: descriptors to scalar registers,
+         * all the group's loads back to back (16 B per lane each), the votes, one copy of the vote loop
+         * per member so that each waits for its own registers only. */
+        uint2 B_ru = make_uint2(0, 0), B_inf = make_uint2(0, 0);
+        auto bperm = [&](uint32_t from_lane, uint32_t v) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
+        };
+        /* step g of a window: its descriptor from lane g of the window's registers (VOTE_GROUP divides 64, so a
+         * group never runs past lane 63; lanes past the window's end describe empty steps) */
+        auto step_at = [&](uint32_t ve0, uint32_t vleft, uint32_t vh0, uint32_t vmisc, int l) -> VoteStep {
+            VoteStep d;
+            const uint32_t misc = readlane_u(vmisc, l);
+            d.e0 = readlane_u(ve0, l);
+            d.left = readlane_u(vleft, l);
+            d.h0 = readlane_u(vh0, l);
+            d.R = (misc & 63u) + 1u;
+            d.i0 = (misc >> 6) & 127u;
+            d.i1 = (misc >> 13) & 127u;
+            d.valid = true;
+            return d;
+        };
+        /* hit ranges a chunk of an item with R hits is cut into, as a shift: giants only */
+        auto split_of = [&](uint32_t R, bool split) -> uint32_t { return !split ? 0u : R > 32u ? 2u : R > 16u ? 1u : 0u; };
+        /* votes the units u0, u0 + stride, ... of the items in the lanes where `take` holds */
+        auto vote_set = [&](bool take, bool split, uint32_t u0, uint32_t stride) {
+            uint32_t excl, incl;
+            {
+                const uint32_t R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+                const uint32_t nu = take ? (((B_inf.y & 0x7fffffffu) + 255u) >> 8) << split_of(R, split) : 0u;
+                incl = nu;
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o, WAVE);
+                    if (lane >= o) incl += up;
+                }
+                excl = incl - nu;
+            }
+            const uint32_t total = readlane_u(incl, WAVE - 1);
+            for (uint32_t ub = u0; ub < total; ub += stride * WAVE) {
+                /* ---- the window: lane i <-> unit ub + stride * i ---- */
+                const uint32_t u = ub + stride * (uint32_t)lane;
+                const bool act = u < total;
+                uint32_t lo = 0;                                   /* items whose running sum is <= u: the unit's item */
+    #pragma unroll
+                for (uint32_t s2 = WAVE / 2; s2 > 0; s2 >>= 1) lo += bperm(lo + s2 - 1u, incl) <= u ? s2 : 0u;
+                lo = lo < (uint32_t)WAVE - 1u ? lo : (uint32_t)WAVE - 1u;
+                const uint32_t st = bperm(lo, B_inf.x), ln = bperm(lo, B_inf.y) & 0x7fffffffu, h0 = bperm(lo, B_ru.y) & 0x7fffffffu;
+                const uint32_t R = (bperm(lo, B_ru.x) >> OSLAMK_RUN_SHIFT) + 1u, lg = split_of(R, split);
+                const uint32_t local = u - bperm(lo, excl);
+                const uint32_t c = local >> lg, hs = local & ((1u << lg) - 1u), per = (R + (1u << lg) - 1u) >> lg;
+                const uint32_t i0 = hs * per, i1 = i0 + per < R ? i0 + per : R;
+                /* a lane past the end describes a step that loads entry 0 and hit 0 and votes nothing */
+                const uint32_t w_e0 = act ? st + (c << 8) : 0u, w_left = act ? ln - (c << 8) : 0u, w_h0 = act ? h0 : 0u,
+                               w_misc = act ? (R - 1u) | (i0 << 6) | (i1 << 13) : 0u;
+                const uint32_t rest = (total - ub + stride - 1u) / stride, n_w = rest < (uint32_t)WAVE ? rest : (uint32_t)WAVE;
+                for (uint32_t g0 = 0; g0 < n_w; g0 += VOTE_GROUP) {
+                    VR regs[VOTE_GROUP];
+                    VoteStep ds[VOTE_GROUP];
+    #pragma unroll
+                    for (int g = 0; g < VOTE_GROUP; g++) {
+                        ds[g] = step_at(w_e0, w_left, w_h0, w_misc, (int)g0 + g);
+                        regs[g].load(e4, hits, ds[g], lane);
+                    }
+                    asm volatile("" ::: "memory");      /* all the group's loads are issued here, in this order: none sinks into its vote */
+    #pragma unroll
+                    for (int g = 0; g < VOTE_GROUP; g++) sq_n = regs[g].vote(sc, acc, s_tbl, sq, sq_n, ds[g], lane, inc_lo, inc_hi);
+                }
+            }
+        };
+        auto marked = [&](const uint2 &ru, const uint2 &inf) -> bool { return MODE == 0 && ((inf.y | ru.y) >> 31); };
+
+        /* ---- the sets, one after the other (one call site of vote_set: its vote loops exist once) ----
+         * giants first: 64 queued items at a time, their units dealt round-robin to the waves;
+         * then the rest, dynamically: VOTE_BLOCK runs at a time from a counter in LDS.  Four blocks sit side by
+         * side in the lanes of B_ru / B_inf (block b in lanes 16 * (b's turn mod 4) ..): the one being voted, the
+         * next (its bucket records in flight) and the one after it (its run records in flight) */
         {
-            const uint32_t R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
-            const uint32_t nu = take ? (((B_inf.y & 0x7fffffffu) + 255u) >> 8) << split_of(R, split) : 0u;
-            incl = nu;
+            const uint32_t n_blocks = (n_runs + VOTE_BLOCK - 1) / VOTE_BLOCK;
+            const uint32_t my_slot = (uint32_t)lane / VOTE_BLOCK, k_in = (uint32_t)lane % VOTE_BLOCK;
+            auto grab = [&]() -> uint32_t {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&s_next, 1u);
+                return uni_u32(readlane_u(b, 0));
+            };
+            /* run records of block b into the lanes of `slot` (zeros past the end of the run list) */
+            auto fetch_runs = [&](uint32_t b, uint32_t slot) {
+                if (my_slot == slot) {
+                    const uint32_t k = b * VOTE_BLOCK + k_in;
+                    B_ru = make_uint2(0, 0);
+                    B_inf = make_uint2(0, 0);
+                    if (k < n_runs) {
+                        const oslamk_run rr = runs[k];
+                        B_ru = make_uint2(rr.slot_r, rr.first);
+                    }
+                }
+            };
+            /* bucket records of the block in `slot` (its run records have landed) */
+            auto fetch_info = [&](uint32_t b, uint32_t slot) {
+                if (my_slot == slot && b * VOTE_BLOCK + k_in < n_runs) {
+                    const oslamk_uinfo ui = uinfo[B_ru.x & RUN_SLOT_MASK];
+                    B_inf = make_uint2(ui.start, ui.len);
+                }
+            };
+            uint32_t cur_b = 0, nx1_b = 0, nx2_b = 0, turn = 0;
+            uint32_t tw = 0;                                 /* giants: first queue entry of the next set */
+            bool started = false;
+            for (;;) {
+                bool take, split;
+                uint32_t u0, stride;
+                if (tw < n_q) {
+                    const uint32_t t = tw + (uint32_t)lane;
+                    B_ru = make_uint2(0, 0);
+                    B_inf = make_uint2(0, 0);
+                    if (t < n_q) {
+                        const oslamk_run rr = runs[s_q[t]];
+                        const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
+                        B_ru = make_uint2(rr.slot_r, rr.first);
+                        B_inf = make_uint2(ui.start, ui.len);
+                    }
+                    tw += WAVE;
+                    take = t < n_q;
+                    split = true;
+                    u0 = uni_u32((uint32_t)wid);
+                    stride = VOTE_THREADS / WAVE;
+                } else {
+                    if (!started) {                          /* the first three blocks of this wave */
+                        started = true;
+                        cur_b = grab();
+                        fetch_runs(cur_b, 0u);
+                        nx1_b = grab();
+                        fetch_runs(nx1_b, 1u);
+                        nx2_b = grab();
+                        fetch_runs(nx2_b, 2u);
+                        fetch_info(cur_b, 0u);
+                        fetch_info(nx1_b, 1u);
+                    }
+                    if (cur_b >= n_blocks) break;            /* the counter only grows: this wave is done */
+                    const uint32_t ln = B_inf.y & 0x7fffffffu, R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
+                    /* of the current block: present in the slice, not a giant (those are done), no marker (those come last) */
+                    take = my_slot == (turn & 3u) && ln != 0u && ((ln + 255u) >> 8) * R <= T && !marked(B_ru, B_inf);
+                    split = false;
+                    u0 = 0u;
+                    stride = 1u;
+                    /* the next blocks move up before the votes, so that their loads fly meanwhile */
+                    cur_b = nx1_b;
+                    nx1_b = nx2_b;
+                    fetch_info(nx1_b, (turn + 2u) & 3u);
+                    nx2_b = grab();
+                    fetch_runs(nx2_b, (turn + 3u) & 3u);
+                    turn++;
+                }
+                vote_set(take, split, u0, stride);
+            }
+        }
+        if (MODE == 0) {
+            /* the items with a marker, dealt round-robin to the waves: every vote through the queue */
+            for (uint32_t k0 = (uint32_t)wid * WAVE; k0 < n_runs; k0 += VOTE_THREADS) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                oslamk_run rr;
+                oslamk_uinfo ui;
+                rr.slot_r = rr.first = 0;
+                ui.start = ui.len = 0;
+                if (k < n_runs) {
+                    rr = runs[k];
+                    ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
+                }
+                unsigned long long fm = __ballot((ui.len & 0x7fffffffu) != 0u && ((ui.len | rr.first) >> 31));
+                while (fm) {
+                    const int j = __ffsll((long long)fm) - 1;
+                    fm &= fm - 1ull;
+                    sq_n = forced_item((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, readlane_u(ui.start, j),
+                                       readlane_u(ui.len, j) & 0x7fffffffu, readlane_u(rr.first, j) & 0x7fffffffu,
+                                       (readlane_u(rr.slot_r, j) >> OSLAMK_RUN_SHIFT) + 1u, lane);
+                }
+            }
+            if (sq_n) slow_queue_flush((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, lane);
+        }
+#ifdef VOTE_PROF
+        const long long pt1 = clock64();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the atomics issued from asm (VoteRegs::vote) */
+        __syncthreads();
+#ifdef VOTE_PROF
+        const long long pt2 = clock64();
+        if (lane == 0) {
+            atomicAdd(&a.counters->prof[0], (unsigned long long)(pt1 - pt0));
+            atomicAdd(&a.counters->prof[1], (unsigned long long)(pt2 - pt0));
+        }
+#endif
+
+
+        /* ---- peak extraction: local max, non-empty cells, sum, emission ---- */
+        /* the two counters of word w: of the model points m_base + row and m_base + 1023 + row */
+        auto lower_of = [&](uint32_t w) -> uint32_t { return pass == 0 ? w & 0xffffu : pass == 1 ? w : 0u; };
+        auto upper_of = [&](uint32_t w) -> uint32_t { return pass == 0 ? w >> 16 : pass == 2 ? w : 0u; };
+        uint32_t lmax = 0, nz = 0;
+        unsigned long long sum = 0;
+#pragma unroll 2
+        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
+            const uint32_t w = acc[c], v0 = lower_of(w), v1 = upper_of(w);
+            lmax = max(lmax, max(v0, v1));
+            nz += (v0 != 0) + (v1 != 0);
+            sum += (unsigned long long)v0 + v1;
+        }
+        lmax = wave_max_u32(lmax);
+        nz = wave_sum_u32(nz);
+        sum = wave_sum_u64(sum);
+        if (lane == 0) {
+            s_wave[wid] = lmax;
+            s_wave2[wid] = nz;
+            s_sum[wid] = sum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t m = 0, n = 0;
+            unsigned long long tot = 0;
+            for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
+                m = s_wave[w] > m ? s_wave[w] : m;
+                n += s_wave2[w];
+                tot += s_sum[w];
+            }
+            /* every vote cast is in a counter unless a 16-bit counter overflowed */
+            s_redo = pass == 0 && tot != s_tot[0] - s_ctx.dropped;
+            if (s_redo) {
+                a.redo[atomicAdd(&a.counters->redo_count, 1u)] = wg;
+                atomicAdd(&a.counters->redo_total, 1u);
+            }
+            if (!s_redo) {
+                if (pass <= 1) {                /* once per workgroup */
+                    /* hits are counted once per reference point */
+                    const unsigned long long h = slice == 0 ? (unsigned long long)a.hit_count[ref_local] : 0ull;
+                    if (h) atomicAdd(&a.counters->hits, h);
+                    if (s_tot[0]) atomicAdd(&a.counters->votes, s_tot[0]);
+                    if (s_tot[1]) {
+                        atomicAdd(&a.counters->entries, s_tot[1] & 0xffffffffffull);
+                        atomicAdd(&a.counters->items, s_tot[1] >> 40);
+                    }
+                }
+                uint32_t g = a.fixed_gmax;
+                if (g == 0) {
+                    const uint32_t old = atomicMax(&a.counters->gmax, m);
+                    g = old > m ? old : m;
+                }
+                if (n) atomicAdd(&a.counters->nonzero_cells, (unsigned long long)n);
+                s_g = g;
+                s_lmax = m;
+            }
+        }
+        __syncthreads();
+        if (s_redo) return;                         /* workgroup-uniform: k_vote_wide takes over */
+
+        if (a.acc_dump && ref_ord == a.dump_ref) {
+            uint32_t *dst = a.acc_dump + (size_t)m_base * OSLAMK_NBIN;
+    #pragma unroll 2
+        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
+                const uint32_t w = acc[c];
+                if (pass <= 1) dst[c] = lower_of(w);
+                if (pass != 1) dst[c + ACC_REAL_CELLS] = upper_of(w);
+            }
+        }
+
+        /* cells with count > thresh * g (model.cu:164-167; g <= final maximum, so
+         * this is a superset that the host filters with the final maximum) */
+        const float bound = a.thresh * (float)s_g;
+        if ((float)s_lmax > bound) {                 /* workgroup-uniform */
+            uint32_t cnt = 0;
+    #pragma unroll 2
+        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
+                const uint32_t w = acc[c];
+                cnt += ((float)lower_of(w) > bound) + ((float)upper_of(w) > bound);
+            }
+            /* exclusive scan of cnt over the workgroup */
+            uint32_t incl = cnt;
             for (int o = 1; o < WAVE; o <<= 1) {
                 const uint32_t up = __shfl_up(incl, o, WAVE);
                 if (lane >= o) incl += up;
             }
-            excl = incl - nu;
-        }
-        const uint32_t total = readlane_u(incl, WAVE - 1);
-        for (uint32_t ub = u0; ub < total; ub += stride * WAVE) {
-            /* ---- the window: lane i <-> unit ub + stride * i ---- */
-            const uint32_t u = ub + stride * (uint32_t)lane;
-            const bool act = u < total;
-            uint32_t lo = 0;                                   /* items whose running sum is <= u: the unit's item */
-#pragma unroll
-            for (uint32_t s2 = WAVE / 2; s2 > 0; s2 >>= 1) lo += bperm(lo + s2 - 1u, incl) <= u ? s2 : 0u;
-            lo = lo < (uint32_t)WAVE - 1u ? lo : (uint32_t)WAVE - 1u;
-            const uint32_t st = bperm(lo, B_inf.x), ln = bperm(lo, B_inf.y) & 0x7fffffffu, h0 = bperm(lo, B_ru.y) & 0x7fffffffu;
-            const uint32_t R = (bperm(lo, B_ru.x) >> OSLAMK_RUN_SHIFT) + 1u, lg = split_of(R, split);
-            const uint32_t local = u - bperm(lo, excl);
-            const uint32_t c = local >> lg, hs = local & ((1u << lg) - 1u), per = (R + (1u << lg) - 1u) >> lg;
-            const uint32_t i0 = hs * per, i1 = i0 + per < R ? i0 + per : R;
-            /* a lane past the end describes a step that loads entry 0 and hit 0 and votes nothing */
-            const uint32_t w_e0 = act ? st + (c << 8) : 0u, w_left = act ? ln - (c << 8) : 0u, w_h0 = act ? h0 : 0u,
-                           w_misc = act ? (R - 1u) | (i0 << 6) | (i1 << 13) : 0u;
-            const uint32_t rest = (total - ub + stride - 1u) / stride, n_w = rest < (uint32_t)WAVE ? rest : (uint32_t)WAVE;
-            for (uint32_t g0 = 0; g0 < n_w; g0 += VOTE_GROUP) {
-                VR regs[VOTE_GROUP];
-                VoteStep ds[VOTE_GROUP];
-#pragma unroll
-                for (int g = 0; g < VOTE_GROUP; g++) {
-                    ds[g] = step_at(w_e0, w_left, w_h0, w_misc, (int)g0 + g);
-                    regs[g].load(e4, hits, ds[g], lane);
+            if (lane == WAVE - 1) s_wave[wid] = incl;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t run = 0;
+                for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
+                    const uint32_t v = s_wave[w];
+                    s_wave[w] = run;
+                    run += v;
                 }
-                asm volatile("" ::: "memory");      /* all the group's loads are issued here, in this order: none sinks into its vote */
-#pragma unroll
-                for (int g = 0; g < VOTE_GROUP; g++) sq_n = regs[g].vote(sc, acc, s_tbl, sq, sq_n, ds[g], lane);
+                s_base = atomicAdd(&a.counters->out_count, run);
             }
-        }
-    };
-    auto marked = [&](const uint2 &ru, const uint2 &inf) -> bool { return MODE == 0 && ((inf.y | ru.y) >> 31); };
-
-    /* ---- the sets, one after the other (one call site of vote_set: its vote loops exist once) ----
-     * giants first: 64 queued items at a time, their units dealt round-robin to the waves;
-     * then the rest, dynamically: VOTE_BLOCK runs at a time from a counter in LDS.  Four blocks sit side by
-     * side in the lanes of B_ru / B_inf (block b in lanes 16 * (b's turn mod 4) ..): the one being voted, the
-     * next (its bucket records in flight) and the one after it (its run records in flight) */
-    {
-        const uint32_t n_blocks = (n_runs + VOTE_BLOCK - 1) / VOTE_BLOCK;
-        const uint32_t my_slot = (uint32_t)lane / VOTE_BLOCK, k_in = (uint32_t)lane % VOTE_BLOCK;
-        auto grab = [&]() -> uint32_t {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(&s_next, 1u);
-            return uni_u32(readlane_u(b, 0));
-        };
-        /* run records of block b into the lanes of `slot` (zeros past the end of the run list) */
-        auto fetch_runs = [&](uint32_t b, uint32_t slot) {
-            if (my_slot == slot) {
-                const uint32_t k = b * VOTE_BLOCK + k_in;
-                B_ru = make_uint2(0, 0);
-                B_inf = make_uint2(0, 0);
-                if (k < n_runs) {
-                    const oslamk_run rr = runs[k];
-                    B_ru = make_uint2(rr.slot_r, rr.first);
-                }
-            }
-        };
-        /* bucket records of the block in `slot` (its run records have landed) */
-        auto fetch_info = [&](uint32_t b, uint32_t slot) {
-            if (my_slot == slot && b * VOTE_BLOCK + k_in < n_runs) {
-                const oslamk_uinfo ui = uinfo[B_ru.x & RUN_SLOT_MASK];
-                B_inf = make_uint2(ui.start, ui.len);
-            }
-        };
-        uint32_t cur_b = 0, nx1_b = 0, nx2_b = 0, turn = 0;
-        uint32_t tw = 0;                                 /* giants: first queue entry of the next set */
-        bool started = false;
-        for (;;) {
-            bool take, split;
-            uint32_t u0, stride;
-            if (tw < n_q) {
-                const uint32_t t = tw + (uint32_t)lane;
-                B_ru = make_uint2(0, 0);
-                B_inf = make_uint2(0, 0);
-                if (t < n_q) {
-                    const oslamk_run rr = runs[s_q[t]];
-                    const oslamk_uinfo ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
-                    B_ru = make_uint2(rr.slot_r, rr.first);
-                    B_inf = make_uint2(ui.start, ui.len);
-                }
-                tw += WAVE;
-                take = t < n_q;
-                split = true;
-                u0 = uni_u32((uint32_t)wid);
-                stride = VOTE_THREADS / WAVE;
-            } else {
-                if (!started) {                          /* the first three blocks of this wave */
-                    started = true;
-                    cur_b = grab();
-                    fetch_runs(cur_b, 0u);
-                    nx1_b = grab();
-                    fetch_runs(nx1_b, 1u);
-                    nx2_b = grab();
-                    fetch_runs(nx2_b, 2u);
-                    fetch_info(cur_b, 0u);
-                    fetch_info(nx1_b, 1u);
-                }
-                if (cur_b >= n_blocks) break;            /* the counter only grows: this wave is done */
-                const uint32_t ln = B_inf.y & 0x7fffffffu, R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u;
-                /* of the current block: present in the slice, not a giant (those are done), no marker (those come last) */
-                take = my_slot == (turn & 3u) && ln != 0u && ((ln + 255u) >> 8) * R <= T && !marked(B_ru, B_inf);
-                split = false;
-                u0 = 0u;
-                stride = 1u;
-                /* the next blocks move up before the votes, so that their loads fly meanwhile */
-                cur_b = nx1_b;
-                nx1_b = nx2_b;
-                fetch_info(nx1_b, (turn + 2u) & 3u);
-                nx2_b = grab();
-                fetch_runs(nx2_b, (turn + 3u) & 3u);
-                turn++;
-            }
-            vote_set(take, split, u0, stride);
-        }
-    }
-    if (MODE == 0) {
-        /* the items with a marker, dealt round-robin to the waves: every vote through the queue */
-        for (uint32_t k0 = (uint32_t)wid * WAVE; k0 < n_runs; k0 += VOTE_THREADS) {
-            const uint32_t k = k0 + (uint32_t)lane;
-            oslamk_run rr;
-            oslamk_uinfo ui;
-            rr.slot_r = rr.first = 0;
-            ui.start = ui.len = 0;
-            if (k < n_runs) {
-                rr = runs[k];
-                ui = uinfo[rr.slot_r & RUN_SLOT_MASK];
-            }
-            unsigned long long fm = __ballot((ui.len & 0x7fffffffu) != 0u && ((ui.len | rr.first) >> 31));
-            while (fm) {
-                const int j = __ffsll((long long)fm) - 1;
-                fm &= fm - 1ull;
-                sq_n = forced_item((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, readlane_u(ui.start, j),
-                                   readlane_u(ui.len, j) & 0x7fffffffu, readlane_u(rr.first, j) & 0x7fffffffu,
-                                   (readlane_u(rr.slot_r, j) >> OSLAMK_RUN_SHIFT) + 1u, lane);
-            }
-        }
-        if (sq_n) slow_queue_flush((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, lane);
-    }
-#ifdef VOTE_PROF
-    const long long pt1 = clock64();
-#endif
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the atomics issued from asm (VoteRegs::vote) */
-    __syncthreads();
-#ifdef VOTE_PROF
-    const long long pt2 = clock64();
-    if (lane == 0) {
-        atomicAdd(&a.counters->prof[0], (unsigned long long)(pt1 - pt0));
-        atomicAdd(&a.counters->prof[1], (unsigned long long)(pt2 - pt0));
-    }
-#endif
-
-    /* ---- peak extraction: local max, non-empty cells, emission ---- */
-    uint32_t lmax = 0, nz = 0;
-    for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
-        const uint32_t v = acc[c];
-        lmax = v > lmax ? v : lmax;
-        nz += (v != 0);
-    }
-    lmax = wave_max_u32(lmax);
-    nz = wave_sum_u32(nz);
-    if (lane == 0) {
-        s_wave[wid] = lmax;
-        s_wave2[wid] = nz;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t m = 0, n = 0;
-        /* hits are counted once per reference point */
-        unsigned long long h = slice == 0 ? (unsigned long long)a.hit_count[ref_local] : 0ull, v = 0;
-        for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
-            m = s_wave[w] > m ? s_wave[w] : m;
-            n += s_wave2[w];
-        }
-        v = s_tot[0];
-        if (s_tot[1]) {
-            atomicAdd(&a.counters->entries, s_tot[1] & 0xffffffffffull);
-            atomicAdd(&a.counters->items, s_tot[1] >> 40);
-        }
-        uint32_t g = a.fixed_gmax;
-        if (g == 0) {
-            const uint32_t old = atomicMax(&a.counters->gmax, m);
-            g = old > m ? old : m;
-        }
-        if (h) atomicAdd(&a.counters->hits, h);
-        if (v) atomicAdd(&a.counters->votes, v);
-        if (n) atomicAdd(&a.counters->nonzero_cells, (unsigned long long)n);
-        s_g = g;
-        s_lmax = m;
-    }
-    __syncthreads();
-
-    if (a.acc_dump && ref_ord == a.dump_ref) {
-        uint32_t *dst = a.acc_dump + (size_t)m_base * OSLAMK_NBIN;
-        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) dst[c] = acc[c];
-    }
-
-    /* cells with count > thresh * g (model.cu:164-167; g <= final maximum, so
-     * this is a superset that the host filters with the final maximum) */
-    const float bound = a.thresh * (float)s_g;
-    if ((float)s_lmax > bound) {                 /* workgroup-uniform */
-        uint32_t cnt = 0;
-        for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) cnt += ((float)acc[c] > bound);
-        /* exclusive scan of cnt over the workgroup */
-        uint32_t incl = cnt;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += up;
-        }
-        if (lane == WAVE - 1) s_wave[wid] = incl;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t run = 0;
-            for (int w = 0; w < VOTE_THREADS / WAVE; w++) {
-                const uint32_t v = s_wave[w];
-                s_wave[w] = run;
-                run += v;
-            }
-            s_base = atomicAdd(&a.counters->out_count, run);
-        }
-        __syncthreads();
-        uint32_t pos = s_base + s_wave[wid] + incl - cnt;
+            __syncthreads();
+            uint32_t pos = s_base + s_wave[wid] + incl - cnt;
+    #pragma unroll 2
         for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
-            const uint32_t v = acc[c];
-            if ((float)v > bound) {
-                if (pos < a.out_cap) {
-                    oslamk_cell cell;
-                    const uint32_t m_r = m_base + (uint32_t)(c / OSLAMK_NBIN);
-                    cell.code = ((unsigned long long)r << 32) | (unsigned long long)((m_r << 6) |
-                                                                 (uint32_t)(c % OSLAMK_NBIN));
-                    cell.count = v;
-                    cell.pad = 0;
-                    a.out[pos] = cell;
+                const uint32_t w = acc[c];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const uint32_t v = hf ? upper_of(w) : lower_of(w);
+                    if ((float)v > bound) {
+                        if (pos < a.out_cap) {
+                            oslamk_cell cell;
+                            const uint32_t m_r = m_base + (uint32_t)hf * PC_ROWS_PER_HALF + (uint32_t)(c / OSLAMK_NBIN);
+                            cell.code = ((unsigned long long)r << 32) | (unsigned long long)((m_r << 6) |
+                                                                         (uint32_t)(c % OSLAMK_NBIN));
+                            cell.count = v;
+                            cell.pad = 0;
+                            a.out[pos] = cell;
+                        }
+                        pos++;
+                    }
                 }
-                pos++;
             }
         }
     }
-#ifdef VOTE_PROF
-    if (lane == 0) atomicAdd(&a.counters->prof[2], (unsigned long long)(clock64() - pt2));
-#endif
+}
+
+template <int MODE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
+{
+    vote_body<MODE, 0>(a, blockIdx.x);
+}
+
+/* the workgroups whose 16-bit counters overflowed, again with 32-bit counters for one half of the slice's model
+ * points (see vote_body); a small fixed grid walks the redo list, which is almost always empty */
+#define VOTE_WIDE_GRID 256
+template <int MODE, int PASS>
+__global__ __launch_bounds__(VOTE_THREADS) void k_vote_wide(oslamk_vote_args a)
+{
+    const uint32_t n = a.counters->redo_count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        vote_body<MODE, PASS>(a, a.redo[i]);
+        __syncthreads();                            /* the LDS of this workgroup is reused by the next entry */
+    }
 }
 
 /* --------------------------------------------------------------------------
@@ -1449,10 +1527,15 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream)
     if (a->n_launch <= 0) return 0;
     /* padded to groups of 8 reference points: see the workgroup -> (reference point, slice) map in k_vote */
     dim3 grid((unsigned)(((size_t)a->n_launch + 7) / 8 * 8 * a->table.n_slices));
-    if (a->mode == 0)
+    if (a->mode == 0) {
         hipLaunchKernelGGL(k_vote<0>, grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
-    else
+        hipLaunchKernelGGL((k_vote_wide<0, 1>), dim3(VOTE_WIDE_GRID), dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((k_vote_wide<0, 2>), dim3(VOTE_WIDE_GRID), dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
+    } else {
         hipLaunchKernelGGL(k_vote<1>, grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((k_vote_wide<1, 1>), dim3(VOTE_WIDE_GRID), dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((k_vote_wide<1, 2>), dim3(VOTE_WIDE_GRID), dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
+    }
     return (int)hipGetLastError();
 }
 

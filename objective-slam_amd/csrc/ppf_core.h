@@ -178,18 +178,31 @@ PM_HD uint32_t pc_vote_base_t24(uint32_t theta_v_t22)
     return ((theta_v_t22 + PC_T22_TURN / 2u) << 2) + PC_T24_MARGIN;
 }
 
-/* A model pair entry as the vote kernel streams it: theta_u << 10 | row, row = the model reference
- * point's accumulator row inside its table slice (0..1022; 1023 = the sink row of padding entries).
- * A vote is tm32 = pc_vote_base_t32(theta_v) - word: the angle difference sits in the upper 24 bits
- * (units of 2^-24 turn << 8), and the row bits ride along below them -- they lower the difference by
- * at most 1023/256 = 4 units of 2^-24 turn, which the base centres (+ 512 = 2 units) and the margin of
- * 64 units absorbs: a vote is re-evaluated whenever it lies within 62 units of a bin edge, still 5.5 x
- * the error bound.  Saves the shift of every entry and the select of its row in every step. */
-#define PC_ROW_BITS 10
-#define PC_ROW_MASK 0x3ffu
+/* A model pair entry as the vote kernel streams it: theta_u21 << 11 | half << 10 | row.
+ *   theta_u21 = the entry's angle in units of 2^-21 turn (pc_angle_t22 rounded to even units: the model side
+ *               gives up one bit so that the row field has eleven);
+ *   row       = the accumulator row (0..1022; 1023 = the sink row of padding entries);
+ *   half      = which 16-bit half of the row's counters the model reference point owns: a table slice holds
+ *               2 x 1023 model reference points, two per 32-bit counter word.
+ * A vote is tm32 = pc_vote_base_t32(theta_v) - word: the angle difference sits in the upper 24 bits (units of
+ * 2^-24 turn << 8), and the eleven row bits ride along below them -- they lower the difference by at most
+ * 2047/256 = 8 units of 2^-24 turn, which the base centres (+ 1024 = 4 units).  Error budget against the
+ * reference's alpha, in units of 2^-24 turn (one unit = 1.79e-6 bin): 11.2 for everything of DESIGN.md 5 with
+ * both angles at 2^-22 turn, + 2 for the coarser model angle, + 4 for the row bits = 17.2; the margin is 64:
+ * a vote is re-evaluated whenever it lies within 60 units of a bin edge, 3.5 x the budget (4.5 x without the
+ * worst-case stacking of the row bits).  math_exhaustive `hybrid` runs exactly this arithmetic. */
+#define PC_ROW_BITS 11
+#define PC_ROW_MASK 0x7ffu
+#define PC_ROW10_MASK 0x3ffu
+#define PC_ROW_HALF_BIT 10
 #define PC_ROW_SINK 1023u
-PM_HD uint32_t pc_entry_word(uint32_t theta_u_t22, uint32_t row) { return (theta_u_t22 << PC_ROW_BITS) | row; }
-PM_HD uint32_t pc_vote_base_t32(uint32_t theta_v_t22) { return (pc_vote_base_t24(theta_v_t22) << 8) + 512u; }
+#define PC_ROWS_PER_HALF 1023u
+PM_HD uint32_t pc_theta_u21(uint32_t theta_t22) { return ((theta_t22 + 1u) >> 1) & (PC_T22_TURN / 2u - 1u); }
+PM_HD uint32_t pc_entry_word(uint32_t theta_u_t22, uint32_t row11) { return (pc_theta_u21(theta_u_t22) << PC_ROW_BITS) | row11; }
+/* row field of the model reference point with index `local` (0 .. 2*1023-1) inside its slice */
+PM_HD uint32_t pc_row11(uint32_t local) { return ((local / PC_ROWS_PER_HALF) << PC_ROW_HALF_BIT) | (local % PC_ROWS_PER_HALF); }
+PM_HD uint32_t pc_local_of_row11(uint32_t row11) { return (row11 >> PC_ROW_HALF_BIT) * PC_ROWS_PER_HALF + (row11 & PC_ROW10_MASK); }
+PM_HD uint32_t pc_vote_base_t32(uint32_t theta_v_t22) { return (pc_vote_base_t24(theta_v_t22) << 8) + 1024u; }
 
 /* the reference's bin from the stored quantities (host-side statement of what the
  * vote kernel does; used by the CPU check of the scheme) for an entry in accumulator row `row`.
@@ -203,7 +216,7 @@ PM_HD unsigned pc_alpha_bin_hybrid_ex(float uy, float uz, float vy, float vz, ui
     const uint64_t prod = (uint64_t)tm32 * 30u;           /* bin * 2^32 + position inside the (shifted) bin */
     const int slow = cs == PC_T22_FORCE || am == PC_T22_FORCE || (uint32_t)prod < PC_T24_EDGE;
     if (needs_exact) *needs_exact = slow;
-    if (pos_bins) *pos_bins = (double)((((cs + PC_T22_TURN / 2u) << 2) - (am << 2)) & 0xffffffu) * 30.0 / 16777216.0;
+    if (pos_bins) *pos_bins = (double)((((cs + PC_T22_TURN / 2u) << 2) - (pc_theta_u21(am) << 3)) & 0xffffffu) * 30.0 / 16777216.0;
     if (slow) return pc_alpha_bin_table(uy, uz, vy, vz, tbl);
     return (unsigned)(prod >> 32);
 }

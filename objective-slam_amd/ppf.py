@@ -42,11 +42,11 @@ class Stats(C.Structure):
                 ("num_unique_votes", C.c_uint64), ("num_model_keys", C.c_uint64), ("num_top", C.c_uint64),
                 ("max_count", C.c_uint32), ("num_emitted", C.c_uint32), ("ms_vote", C.c_float),
                 ("ms_total", C.c_float), ("vote_launches", C.c_uint32), ("ms_vote_kernel", C.c_float),
-                ("ms_key_kernel", C.c_float), ("reserved0", C.c_uint32), ("num_pairs_probed", C.c_uint64),
+                ("ms_key_kernel", C.c_float), ("wide_workgroups", C.c_uint32), ("num_pairs_probed", C.c_uint64),
                 ("scratch_bytes", C.c_uint64), ("num_entries_streamed", C.c_uint64), ("num_items", C.c_uint64)]
 
     def asdict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved0"}
+        return {f: getattr(self, f) for f, _ in self._fields_}
 
 
 CELL_DTYPE = np.dtype([("code", "<u8"), ("count", "<u4"), ("pad", "<u4")])

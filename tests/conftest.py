@@ -61,8 +61,8 @@ def case_small(synth):
 
 @pytest.fixture(scope="session")
 def case_two_slices(synth):
-    # M > 1024: two table slices / two LDS accumulators per reference point
-    return make_case(synth, 1300, 1500, 2002)
+    # M > 2046: two table slices / two LDS accumulators per reference point (both 16-bit halves of the first in use)
+    return make_case(synth, 2300, 1500, 2002)
 
 
 def cells_equal(a, b):

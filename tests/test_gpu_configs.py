@@ -362,3 +362,45 @@ def test_align_multi_on_a_communicator_of_one(ppf, oracle, built_lib, case_small
     with pytest.raises(ppf.OslamError):
         mo.align_multi(ppf.Scene(case_small["sp"], case_small["sn"], d_dist=case_small["d"], params=par), comm)
     comm.close()
+
+
+def _arc_cloud(n, rng, spread=0.15):
+    """A point at the origin and n points on a short arc of radius 1 around it, all normals +z: every (origin, arc)
+    pair has the same key and nearly the same in-plane angle."""
+    a = rng.uniform(-spread, spread, n)
+    p = np.zeros((n + 1, 3), np.float32)
+    p[1:, 0] = np.cos(a)
+    p[1:, 1] = np.sin(a)
+    p[1:, 2] = rng.uniform(-1e-3, 1e-3, n)
+    return p, np.tile(np.float32([0, 0, 1]), (n + 1, 1))
+
+
+@pytest.mark.parametrize("filler", [0, 1040])
+def test_counters_beyond_16_bits(ppf, oracle, built_lib, filler):
+    """The accumulator keeps two 16-bit counters per word; a workgroup whose counters overflow notices (the sum of
+    its counters falls short of the votes it cast) and is voted again with 32-bit counters, one half at a time.
+    Arc clouds put ~2.8e5 votes into single cells (more than four times what 16 bits hold): the dense accumulator,
+    the peak cells, the statistics and the pose still equal the oracle's, and the statistics say that the wide passes
+    ran.  With filler points in front the overflowing rows lie in the upper half of a word."""
+    rng = np.random.default_rng(5)
+    mp, mn = _arc_cloud(159, rng)
+    sp, sn = _arc_cloud(2999, rng)
+    if filler:
+        fp = rng.uniform(5, 6, (filler, 3)).astype(np.float32)
+        fn = rng.normal(size=(filler, 3)).astype(np.float32)
+        fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+        mp, mn = np.concatenate([fp, mp]), np.concatenate([fn, mn])
+    d = 0.3
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=1500)
+    mo = ppf.Model(mp, mn, d_dist=d)
+    acc = mo.vote_accumulator(sc, 0)
+    assert acc.max() > 3 * 65535
+    assert np.array_equal(acc, oracle.accumulator_for_ref(mp, mn, sp, sn, 0, d))
+    T = mo.ppf_lookup(sc)
+    assert mo.stats["wide_workgroups"] > 0 and mo.stats["max_count"] > 4 * 65535
+    ocells, ost = oracle.votes_fused(mp, mn, sp, sn, 1500, d, 0.4)
+    assert cells_equal(mo.last_cells()[0], ocells)
+    for k in ("num_votes", "num_unique_votes", "max_count", "num_hits"):
+        assert mo.stats[k] == ost[k], k
+    _, To = oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)
+    assert np.array_equal(T, To)
