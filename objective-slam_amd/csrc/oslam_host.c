@@ -348,6 +348,7 @@ void oslam_model_destroy(oslam_model *m)
     if (m->ent.mi) (void)hipFree(m->ent.mi);
     if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
     if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
+    if (m->table.kmap && !m->shared_union) (void)hipFree(m->table.kmap);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_union) (void)hipFree(m->d_union);
@@ -364,6 +365,31 @@ void oslam_model_destroy(oslam_model *m)
     free(m);
 }
 
+/* table.kmap and table.reach_words from table.ukeys / table.reach (both complete on g_stream): the slot of every
+ * key a reachable distance bin can produce, so that the scene-key kernel looks a pair up with one load.  17^3
+ * words per reachable distance bin (0.8 MB for a model that spans 41 bins). */
+static int build_kmap(oslamk_table *t, float d_dist)
+{
+    int rc = OSLAM_OK;
+    uint32_t h_reach[OSLAMK_REACH_BINS / 32], w, top = 0;
+    t->kmap = NULL;
+    t->kmap_bins = 0;
+    t->reach_words = 0;
+    HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    HIPCHK(hipMemcpy(h_reach, t->reach, sizeof h_reach, hipMemcpyDeviceToHost));
+    for (w = 0; w < OSLAMK_REACH_BINS / 32; w++)
+        if (h_reach[w]) {
+            t->reach_words = w + 1;
+            top = 32u * w + (32u - (uint32_t)__builtin_clz(h_reach[w]));    /* highest reachable bin + 1 */
+        }
+    t->kmap_bins = top < OSLAMK_KMAP_MAX_BINS ? top : OSLAMK_KMAP_MAX_BINS;
+    if (t->kmap_bins == 0) return OSLAM_OK;
+    HIPCHK(hipMalloc((void **)&t->kmap, sizeof(uint32_t) * (size_t)t->kmap_bins * PC_ANGLE_COMBOS));
+    KCHK(oslamk_kmap_build(*t, d_dist, g_stream));
+done:
+    return rc;
+}
+
 /* table.ukeys (every distinct key of the model once, at most a quarter full; `distinct` = an upper bound of
  * their number) and table.reach (the distance bins that can produce a key); d_n_keys / d_overflow: device words */
 static int build_union(oslam_model *m, uint32_t distinct, uint32_t *d_n_keys, uint32_t *d_overflow)
@@ -374,8 +400,10 @@ static int build_union(oslam_model *m, uint32_t distinct, uint32_t *d_n_keys, ui
     if ((1u << lg) < 2u * distinct) return fail(OSLAM_E_LIMIT, "more distinct pair keys than the union table can index");
     if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
     if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
+    if (m->table.kmap && !m->shared_union) (void)hipFree(m->table.kmap);
     m->table.ukeys = NULL;
     m->table.reach = NULL;
+    m->table.kmap = NULL;
     m->shared_union = 0;
     m->table.ucap = 1u << lg;
     m->table.ushift = 32 - lg;
@@ -388,6 +416,7 @@ static int build_union(oslam_model *m, uint32_t distinct, uint32_t *d_n_keys, ui
     HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
     HIPCHK(hipMemsetAsync(m->table.reach, 0, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), (hipStream_t)g_stream));
     KCHK(oslamk_reach_build(m->table, m->d_dist, g_stream));
+    rc = build_kmap(&m->table, m->d_dist);
 done:
     return rc;
 }
@@ -721,6 +750,8 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     if (sum != hd.checksum) { rc = fail(OSLAM_E_INVALID, "model file checksum mismatch"); goto done; }
     m->h_slots = h_slots;                         /* the bucket tap reads it */
     h_slots = NULL;
+    rc = build_kmap(&m->table, m->d_dist);
+    if (rc != OSLAM_OK) goto done;
     rc = build_uinfo(m);
     if (rc != OSLAM_OK) goto done;
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
@@ -1833,7 +1864,7 @@ done:
 typedef struct db_group {
     int n;
     size_t *members;                  /* indices into db->models */
-    uint32_t *ukeys, *reach;          /* the group's union table and reachable-distance bitset (n > 1) */
+    uint32_t *ukeys, *reach, *kmap;   /* the group's union table, reachable-distance bitset and key map (n > 1) */
 } db_group;
 
 struct oslam_db {
@@ -1868,6 +1899,7 @@ void oslam_db_destroy(oslam_db *db)
             (void)hipStreamSynchronize((hipStream_t)g_stream);
             if (gr->ukeys) (void)hipFree(gr->ukeys);
             if (gr->reach) (void)hipFree(gr->reach);
+            if (gr->kmap) (void)hipFree(gr->kmap);
         }
         free(gr->members);
     }
@@ -1935,6 +1967,9 @@ int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
         }
         t.reach = gr->reach;
         KCHK(oslamk_reach_build(t, models[gr->members[0]]->d_dist, g_stream));
+        rc = build_kmap(&t, models[gr->members[0]]->d_dist);
+        gr->kmap = t.kmap;
+        if (rc != OSLAM_OK) goto done;
         HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
         HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
         if (h_small[1]) { rc = fail(OSLAM_E_LIMIT, "union key table overflow"); goto done; }
@@ -1943,8 +1978,12 @@ int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
             oslam_model *m = models[gr->members[k]];
             (void)hipFree(m->table.ukeys);
             (void)hipFree(m->table.reach);
+            if (m->table.kmap) (void)hipFree(m->table.kmap);
             m->table.ukeys = gr->ukeys;
             m->table.reach = gr->reach;
+            m->table.kmap = gr->kmap;
+            m->table.kmap_bins = t.kmap_bins;
+            m->table.reach_words = t.reach_words;
             m->table.ucap = 1u << lg;
             m->table.ushift = 32 - lg;
             m->shared_union = 1;

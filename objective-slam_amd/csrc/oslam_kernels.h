@@ -69,8 +69,16 @@ typedef struct oslamk_table {
     /* reach[k1 / 32] bit k1 % 32: some key of the model can come from a pair in distance bin k1
      * (FNV collisions included), k1 < OSLAMK_REACH_BINS; pairs in other bins cannot hit */
     uint32_t *reach;
+    uint32_t reach_words;      /* words of `reach` up to and including the last one that has a bit set */
+    /* kmap[k1 * 17^3 + combo], k1 < kmap_bins: the union-table slot of the key that distance bin k1 and the
+     * angle bins `combo` hash to (pc_key_of_bins), or OSLAMK_KMAP_NONE; covers every reachable bin unless the
+     * model spans more than OSLAMK_KMAP_MAX_BINS of them (the rest are hashed and probed) */
+    uint32_t *kmap;
+    uint32_t kmap_bins;
     oslamk_uinfo *uinfo;       /* [n_slices][ucap] */
 } oslamk_table;
+#define OSLAMK_KMAP_NONE 0xffffffffu
+#define OSLAMK_KMAP_MAX_BINS 2048
 
 #define OSLAMK_REACH_BINS 16384
 
@@ -108,6 +116,8 @@ int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
 int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream);
 /* fill t.reach by enumerating every key each distance bin can produce */
 int oslamk_reach_build(oslamk_table t, float d_dist, void *stream);
+/* fill t.kmap (t.kmap_bins rows) from t.ukeys */
+int oslamk_kmap_build(oslamk_table t, float d_dist, void *stream);
 /* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed). */
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,
                       const float *tmg, oslamk_entries ent, void *stream);

@@ -184,6 +184,28 @@ __global__ __launch_bounds__(256) void k_reach_build(oslamk_table t, float d_dis
     if (threadIdx.x == 0 && s_found) atomicOr(&t.reach[k1 >> 5], 1u << (k1 & 31u));
 }
 
+/* table.kmap[k1][combo] = the slot in the union table of the key that distance bin k1 and the angle bins
+ * `combo` hash to (pc_key_of_bins), or OSLAMK_KMAP_NONE: the scene-key kernel then needs neither the hash nor
+ * a probe sequence.  One workgroup per distance bin k1 < table.kmap_bins. */
+__global__ __launch_bounds__(256) void k_kmap_build(oslamk_table t, float d_dist)
+{
+    const uint32_t k1 = blockIdx.x, mask = t.ucap - 1;
+    for (uint32_t combo = threadIdx.x; combo < PC_ANGLE_COMBOS; combo += 256) {
+        const uint32_t key = pc_key_of_bins(k1, combo, d_dist);
+        uint32_t found = OSLAMK_KMAP_NONE;
+        if (key != 0) {
+            uint32_t slot = slot_of(key, t.ushift);
+            for (uint32_t probe = 0; probe <= mask; probe++) {
+                const uint32_t k = t.ukeys[slot];
+                if (k == key) { found = slot; break; }
+                if (k == 0) break;
+                slot = (slot + 1) & mask;
+            }
+        }
+        t.kmap[(size_t)k1 * PC_ANGLE_COMBOS + combo] = found;
+    }
+}
+
 /* table.uinfo[slice][slot of the key in the union table] = the key's bucket in that slice: lets the vote
  * kernel go from a hit to its bucket with one load instead of a probe sequence.  One thread per slot of
  * the slice tables; uinfo is zeroed by the host (len 0 = the slice has no pair with that key). */
@@ -582,28 +604,49 @@ struct VoteRegs {
  * scene pair keys -> hit lists (Scene::Scene's key pass, scene.cu:24-55: K1 ppf_kernel + K2
  * ppf_hash_kernel, fused with the lookup of model.cu:96-97)
  * ------------------------------------------------------------------------*/
-#define KEY_TILE 4096
-#define COUNT_REFS 8                   /* reference points one counting workgroup handles against its tile */
+#define KEY_TILE 4096                  /* scene points per counting workgroup */
+#define COUNT_REFS 8                   /* reference points one workgroup handles against its tile */
+#define HIT_TILE 1024                  /* scene points per hit-list workgroup (indices inside it fit 16 bits) */
 
-/* Can the pair (reference point, point at distance vector d) produce a key of the model at all?
- * Exact: table.reach has a bit for every distance bin that holds a model key, FNV collisions
- * included; bins beyond the bitset and non-finite distances are kept. */
-__device__ __forceinline__ bool pair_in_reach(const oslamk_vote_args &a, float dx, float dy, float dz)
+__device__ const uint32_t d_acos_lut[2 * PC_ACOS_CELLS] = {PC_ACOS_LUT_FLAT};
+
+/* The distance bin of a pair, pc_pair_dist_bin's value at a third of its cost: the hardware's approximate
+ * square root (1 ulp) gives the quotient to 3e-7 relative, which decides the bin unless the quotient lies
+ * within 1e-6 relative of a bin edge (or the distance is tiny, huge or not a number) -- those lanes, a few
+ * in a million, take the exact sequence. */
+__device__ __forceinline__ int pair_dist_bin_quick(float dx, float dy, float dz, float d_dist, float inv_d_dist)
 {
-    const int k = pc_pair_dist_bin(dx, dy, dz, a.d_dist, a.inv_d_dist);
-    return (unsigned)k >= OSLAMK_REACH_BINS || ((a.table.reach[k >> 5] >> (k & 31)) & 1u);
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float q = __builtin_amdgcn_sqrtf(d2) * inv_d_dist;
+    const float kf = __builtin_floorf(q);
+    const float fr = q - kf, tol = q * 1e-6f;
+    int k = (int)kf;
+    if (!(d2 > 1e-30f && q < 1048576.0f && fr > tol && 1.0f - fr > tol)) k = pc_pair_dist_bin(dx, dy, dz, d_dist, inv_d_dist);
+    return k;
 }
 
-/* Sizes the hit lists by demand: keep_count[ref] = pairs of the reference point that pass
- * pair_in_reach (what k_scene_hits keys and probes), an upper bound of its hits -- 16 % above them on
- * the bench scene.  A workgroup tests its tile of scene points against COUNT_REFS reference points
- * (their coordinates sit in scalar registers), so a point is loaded once per 8 pairs.
+/* Can a pair in distance bin k produce a key of the model at all?  Exact: table.reach has a bit for every
+ * distance bin that holds a model key, FNV collisions included (`reach` = the workgroup's LDS copy of its first
+ * reach_words words, the rest are zero); bins beyond the bitset and non-finite distances (k < 0) are kept. */
+__device__ __forceinline__ bool bin_in_reach(const uint32_t *reach, uint32_t reach_words, int k)
+{
+    if ((uint32_t)k >= OSLAMK_REACH_BINS) return true;
+    const uint32_t w = (uint32_t)k >> 5;
+    return w < reach_words && ((reach[w] >> ((uint32_t)k & 31u)) & 1u);
+}
+
+/* Sizes the hit lists by demand: keep_count[ref] = pairs of the reference point whose distance bin is within
+ * reach (what k_scene_hits keys and looks up), an upper bound of its hits -- 16 % above them on the bench
+ * scene.  A workgroup tests its tile of scene points against COUNT_REFS reference points (their coordinates
+ * sit in scalar registers), so a point is loaded once per 8 pairs.
  * grid (ceil(n_launch / COUNT_REFS), ceil(S / KEY_TILE)). */
 __global__ __launch_bounds__(256) void k_scene_count(oslamk_vote_args a)
 {
     __shared__ uint32_t s_cnt[COUNT_REFS];
+    __shared__ uint32_t s_reach[OSLAMK_REACH_BINS / 32];
     const int S = a.scene.n, lane = threadIdx.x & (WAVE - 1);
     const int g0 = blockIdx.x * COUNT_REFS;
+    const uint32_t reach_words = a.table.reach_words;
     uint32_t rr[COUNT_REFS], cnt[COUNT_REFS];
     float prx[COUNT_REFS], pry[COUNT_REFS], prz[COUNT_REFS];
 #pragma unroll
@@ -616,6 +659,7 @@ __global__ __launch_bounds__(256) void k_scene_count(oslamk_vote_args a)
         cnt[g] = 0;
     }
     if (threadIdx.x < COUNT_REFS) s_cnt[threadIdx.x] = 0;
+    for (uint32_t w = threadIdx.x; w < reach_words; w += 256) s_reach[w] = a.table.reach[w];
     __syncthreads();
     for (int c = 0; c < KEY_TILE / 256; c++) {
         const int i = blockIdx.y * KEY_TILE + c * 256 + threadIdx.x;
@@ -623,7 +667,8 @@ __global__ __launch_bounds__(256) void k_scene_count(oslamk_vote_args a)
         const float x = in ? a.scene.px[i] : 0.0f, y = in ? a.scene.py[i] : 0.0f, z = in ? a.scene.pz[i] : 0.0f;
 #pragma unroll
         for (int g = 0; g < COUNT_REFS; g++) {
-            const bool keep = in && (uint32_t)i != rr[g] && pair_in_reach(a, x - prx[g], y - pry[g], z - prz[g]);
+            const int k = pair_dist_bin_quick(x - prx[g], y - pry[g], z - prz[g], a.d_dist, a.inv_d_dist);
+            const bool keep = in && (uint32_t)i != rr[g] && bin_in_reach(s_reach, reach_words, k);
             cnt[g] += (uint32_t)__popcll(__ballot(keep));
         }
     }
@@ -637,58 +682,39 @@ __global__ __launch_bounds__(256) void k_scene_count(oslamk_vote_args a)
         atomicAdd(&a.keep_count[g0 + threadIdx.x], s_cnt[threadIdx.x]);
 }
 
-/* The pairs (reference point r, point i) of one tile of KEY_TILE scene points.  Phase 1 (cheap,
- * every pair): distance bin only; pairs that fail pair_in_reach are dropped, the rest are
- * compacted into LDS.  Phase 2 (dense lanes): full key, union-table probe; a pair that hits is
- * appended to r's hit list as {slot of the key in the union table} + {theta_v, i}; one atomic per
- * wave reserves the places.  The list of r has keep_count[r] places (k_scene_count), which phase 1
- * cannot exceed.  grid (refs in this batch, ceil(S/KEY_TILE)). */
-__global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
+/* Phase 2 of k_scene_hits for one wave: up to 64 pairs (reference point ref_local of the batch, point
+ * tile0 + list[j0 + lane]) that are within reach.  The pair's quantised feature as bins (pc_pair_bins: the
+ * reference's operations up to each acosf argument, then the tabulated steps), the slot of its key in the
+ * union table from table.kmap -- one load instead of the hash and a probe sequence -- and for a pair that
+ * hits, theta_v; the hits are appended to the reference point's list, one atomic per wave for the places. */
+__device__ __forceinline__ void hits_chunk(const oslamk_vote_args &a, int ref_local, int tile0, const uint16_t *list,
+                                           uint32_t j0, uint32_t n, const uint32_t *lut, int lane)
 {
-    __shared__ uint32_t s_list[KEY_TILE];
-    __shared__ uint32_t s_n;
-    const int ref_local = blockIdx.x;
     const int ref_ord = a.first_ref + ref_local;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int S = a.scene.n;
     const uint32_t r = a.ref_idx[ref_ord];
     const float prx = a.scene.px[r], pry = a.scene.py[r], prz = a.scene.pz[r];
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-
-    for (int c = 0; c < KEY_TILE / 256; c++) {
-        const int i = blockIdx.y * KEY_TILE + c * 256 + threadIdx.x;
-        bool keep = false;
-        if (i < S && (uint32_t)i != r)
-            keep = pair_in_reach(a, a.scene.px[i] - prx, a.scene.py[i] - pry, a.scene.pz[i] - prz);
-        const unsigned long long km = __ballot(keep);
-        if (km) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__popcll(km));
-            base = readlane_u(base, 0);
-            if (keep) s_list[base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = (uint32_t)i;
-        }
-    }
-    __syncthreads();
-
-    const uint32_t n_keep = s_n;
-    if (n_keep == 0) return;
     const float nrx = a.scene.nx[r], nry = a.scene.ny[r], nrz = a.scene.nz[r];
     const float nrn = pc_norm3(nrx, nry, nrz);
     const float *rows = a.tsg + 8 * (size_t)ref_ord;
-    const uint32_t off = a.hit_off[ref_local];
-    for (uint32_t j0 = 0; j0 < n_keep; j0 += 256) {
-        const uint32_t j = j0 + threadIdx.x;
-        bool hit = false;
-        uint32_t slot = 0;
-        oslamk_pay pay;
-        pay.theta_t22 = 0;
-        pay.idx = 0;
-        if (j < n_keep) {
-            const int i = (int)s_list[j];
-            float x, y, z;
-            const uint32_t key = cloud_pair_key(a.scene, i, prx, pry, prz, nrx, nry, nrz, nrn, a.d_dist,
-                                                a.inv_d_dist, &x, &y, &z);
+    const uint32_t j = j0 + (uint32_t)lane;
+    bool hit = false;
+    uint32_t slot = 0;
+    oslamk_pay pay;
+    pay.theta_t22 = 0;
+    pay.idx = 0;
+    if (j < n) {
+        const int i = tile0 + (int)list[j];
+        const float x = a.scene.px[i], y = a.scene.py[i], z = a.scene.pz[i];
+        const float nx = a.scene.nx[i], ny = a.scene.ny[i], nz = a.scene.nz[i];
+        const float nn = pc_norm3(nx, ny, nz);
+        uint32_t combo;
+        const int k1 = pc_pair_bins(prx, pry, prz, nrx, nry, nrz, nrn, x, y, z, nx, ny, nz, nn, a.d_dist, a.inv_d_dist, lut, &combo);
+        if ((uint32_t)k1 < a.table.kmap_bins) {
+            slot = a.table.kmap[(size_t)k1 * PC_ANGLE_COMBOS + combo];
+            hit = slot != OSLAMK_KMAP_NONE;
+        } else {
+            /* a bin the map does not cover (or pc_pair_key's generic path): hash and probe */
+            const uint32_t key = pc_pair_key(prx, pry, prz, nrx, nry, nrz, nrn, x, y, z, nx, ny, nz, nn, a.d_dist, a.inv_d_dist);
             if (key != 0) {                                       /* kernel.cu:491,520 */
                 const uint32_t mask = a.table.ucap - 1;
                 slot = slot_of(key, a.table.ushift);
@@ -698,25 +724,84 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
                     if (k == 0) break;
                     slot = (slot + 1) & mask;
                 }
-                if (hit) {
-                    const float vy = pc_row_dot(rows, x, y, z);     /* kernel.cu:334-336 */
-                    const float vz = pc_row_dot(rows + 4, x, y, z);
-                    pay.theta_t22 = pc_angle_t22(vy, vz);
-                    pay.idx = (uint32_t)i;
-                }
             }
         }
-        const unsigned long long hm = __ballot(hit);
-        if (hm) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
-            base = readlane_u(base, 0);
-            if (hit) {
-                const size_t pos = (size_t)off + base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-                a.hit_key[pos] = slot;
-                a.hit_pay[pos] = pay;
+        if (hit) {
+            const float vy = pc_row_dot(rows, x, y, z);     /* kernel.cu:334-336 */
+            const float vz = pc_row_dot(rows + 4, x, y, z);
+            pay.theta_t22 = pc_angle_t22(vy, vz);
+            pay.idx = (uint32_t)i;
+        }
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
+        base = readlane_u(base, 0);
+        if (hit) {
+            const size_t pos = (size_t)a.hit_off[ref_local] + base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+            a.hit_key[pos] = slot;
+            a.hit_pay[pos] = pay;
+        }
+    }
+}
+
+/* The pairs (reference point, point) of COUNT_REFS reference points and one tile of HIT_TILE scene points.
+ * Phase 1 (cheap, every pair; a point is loaded once for the 8 reference points): distance bin only; pairs
+ * out of reach are dropped, the rest are compacted into one LDS list per reference point.  Phase 2 (dense
+ * lanes): the waves share out the lists in chunks of 64 pairs (hits_chunk); a pair that hits is appended
+ * to its reference point's hit list as {slot of the key in the union table} + {theta_v, i}.  The list of
+ * a reference point has keep_count[] places (k_scene_count: the same predicate), which phase 1 cannot
+ * exceed.  grid (ceil(n_launch / COUNT_REFS), ceil(S / HIT_TILE)). */
+__global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
+{
+    __shared__ uint16_t s_list[COUNT_REFS][HIT_TILE];
+    __shared__ uint32_t s_n[COUNT_REFS];
+    __shared__ uint32_t s_reach[OSLAMK_REACH_BINS / 32];
+    __shared__ uint32_t s_lut[2 * PC_ACOS_CELLS];
+    const int S = a.scene.n, lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = threadIdx.x >> 6;
+    const int g0 = blockIdx.x * COUNT_REFS, tile0 = blockIdx.y * HIT_TILE;
+    const uint32_t reach_words = a.table.reach_words;
+    uint32_t rr[COUNT_REFS];
+    float prx[COUNT_REFS], pry[COUNT_REFS], prz[COUNT_REFS];
+#pragma unroll
+    for (int g = 0; g < COUNT_REFS; g++) {
+        const bool v = g0 + g < a.n_launch;
+        rr[g] = v ? a.ref_idx[a.first_ref + g0 + g] : 0xffffffffu;
+        prx[g] = v ? a.scene.px[rr[g]] : 0.0f;
+        pry[g] = v ? a.scene.py[rr[g]] : 0.0f;
+        prz[g] = v ? a.scene.pz[rr[g]] : 0.0f;
+    }
+    if (threadIdx.x < COUNT_REFS) s_n[threadIdx.x] = 0;
+    for (uint32_t w = threadIdx.x; w < reach_words; w += 256) s_reach[w] = a.table.reach[w];
+    s_lut[threadIdx.x] = d_acos_lut[threadIdx.x];
+    __syncthreads();
+
+    for (int c = 0; c < HIT_TILE / 256; c++) {
+        const int li = c * 256 + (int)threadIdx.x, i = tile0 + li;
+        const bool in = i < S;
+        const float x = in ? a.scene.px[i] : 0.0f, y = in ? a.scene.py[i] : 0.0f, z = in ? a.scene.pz[i] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < COUNT_REFS; g++) {
+            const int k = pair_dist_bin_quick(x - prx[g], y - pry[g], z - prz[g], a.d_dist, a.inv_d_dist);
+            const bool keep = in && (uint32_t)i != rr[g] && g0 + g < a.n_launch && bin_in_reach(s_reach, reach_words, k);
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_n[g], (uint32_t)__popcll(km));
+                base = readlane_u(base, 0);
+                if (keep) s_list[g][base + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = (uint16_t)li;
             }
         }
+    }
+    __syncthreads();
+
+    uint32_t cc = 0;
+    for (int g = 0; g < COUNT_REFS && g0 + g < a.n_launch; g++) {
+        const uint32_t n_g = uni_u32(s_n[g]);
+        for (uint32_t j0 = 0; j0 < n_g; j0 += WAVE, cc++)
+            if ((cc & 3u) == wave) hits_chunk(a, g0 + g, tile0, &s_list[g][0], j0, n_g, s_lut, lane);
     }
 }
 
@@ -1492,6 +1577,13 @@ int oslamk_reach_build(oslamk_table t, float d_dist, void *stream)
     return (int)hipGetLastError();
 }
 
+int oslamk_kmap_build(oslamk_table t, float d_dist, void *stream)
+{
+    if (t.kmap_bins == 0) return 0;
+    hipLaunchKernelGGL(k_kmap_build, dim3(t.kmap_bins), dim3(256), 0, (hipStream_t)stream, t, d_dist);
+    return (int)hipGetLastError();
+}
+
 int oslamk_uinfo_build(oslamk_table t, void *stream)
 {
     const size_t total = (size_t)t.n_slices * t.cap;
@@ -1510,7 +1602,7 @@ int oslamk_scene_count(const oslamk_vote_args *a, void *stream)
 int oslamk_scene_hits(const oslamk_vote_args *a, void *stream)
 {
     if (a->n_launch <= 0) return 0;
-    dim3 grid((unsigned)a->n_launch, (unsigned)((a->scene.n + KEY_TILE - 1) / KEY_TILE));
+    dim3 grid((unsigned)((a->n_launch + COUNT_REFS - 1) / COUNT_REFS), (unsigned)((a->scene.n + HIT_TILE - 1) / HIT_TILE));
     hipLaunchKernelGGL(k_scene_hits, grid, dim3(256), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }

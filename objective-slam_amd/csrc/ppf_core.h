@@ -11,6 +11,7 @@
 #ifndef OSLAM_PPF_CORE_H
 #define OSLAM_PPF_CORE_H
 
+#include "ppf_acos_table.h"
 #include "ppf_alpha_table.h"
 #include "ppf_math.h"
 
@@ -64,6 +65,37 @@ PM_HD uint32_t pc_pair_key(float p1x, float p1y, float p1z, float n1x, float n1y
     h = pm_fnv1a_word(h, pc_quant_bits(a3, D, invD));
     h = pm_fnv1a_word(h, pc_quant_bits(a4, D, invD));
     return h;
+}
+
+/* floor(acosf(c) / D) of pc_pair_key without evaluating acosf: the bin is a step function of the float c whose
+ * steps were tabulated on every float (ppf_acos_table.h; `lut` = PC_ACOS_LUT or a copy of it).  0..15, or 16
+ * where acosf gives NaN (the reference then hashes the NaN pattern). */
+PM_HD uint32_t pc_acos_bin(float c, const uint32_t *lut)
+{
+    int cell;
+    if (!(pm_fabsf(c) <= 1.0f)) return 16u;
+    cell = (int)(c * 64.0f + 64.0f);
+    cell = cell > PC_ACOS_CELLS - 1 ? PC_ACOS_CELLS - 1 : cell;
+    return lut[2 * cell + 1] + (c <= PM_BITS_U2F(lut[2 * cell]) ? 1u : 0u);
+}
+
+/* The quantised feature of the ordered pair as bins instead of a hash: returns the distance bin k1 and
+ * *combo = j2 + 17*j3 + 289*j4 with pc_pair_key(...) == pc_key_of_bins(k1, *combo, d_dist); -1 where
+ * pc_pair_key takes its generic path (distance NaN, infinite or >= 2^21 bins) and the caller has to as well.
+ * Same operations on the same operands as pc_pair_key up to each acosf argument. */
+PM_HD int pc_pair_bins(float p1x, float p1y, float p1z, float n1x, float n1y, float n1z, float n1n, float p2x,
+                       float p2y, float p2z, float n2x, float n2y, float n2z, float n2n, float d_dist,
+                       float inv_d_dist, const uint32_t *lut, uint32_t *combo)
+{
+    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    float nd = pm_sqrtf(dx * dx + dy * dy + dz * dz);
+    const uint32_t j2 = pc_acos_bin((n1x * dx + n1y * dy + n1z * dz) / (n1n * nd), lut);
+    const uint32_t j3 = pc_acos_bin((n2x * dx + n2y * dy + n2z * dz) / (n2n * nd), lut);
+    const uint32_t j4 = pc_acos_bin((n1x * n2x + n1y * n2y + n1z * n2z) / (n1n * n2n), lut);
+    int k;
+    (void)pm_quant_down_pos(nd, d_dist, inv_d_dist, &k);
+    *combo = j2 + 17u * j3 + 289u * j4;
+    return k;
 }
 
 /* Every key a pair in distance bin k1 can have: the quantised distance is (float)k1 * d_dist

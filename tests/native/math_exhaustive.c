@@ -9,6 +9,10 @@
  *   math_exhaustive alphabin N      pc_alpha_bin_table vs the libm formula of kernel.cu:338-342
  *   math_exhaustive hybrid N        pc_alpha_bin_hybrid vs the same formula; also prints the largest
  *                                   distance between the quantised and the reference position
+ *   math_exhaustive acosbin STRIDE  all floats i*STRIDE: pc_acos_bin (the tabulated steps) vs the quantised libm
+ *                                   acosf, acosf(c) - fmodf(acosf(c), D) == bin * D (or NaN, bin 16)
+ *   math_exhaustive pairbins N      N point pairs (random, near-degenerate and degenerate): the key rebuilt from
+ *                                   pc_pair_bins by pc_key_of_bins vs pc_pair_key
  *
  * Prints "mismatches=K checked=N" and exits non-zero when K != 0.
  * NaN results compare equal when both are NaN (payload is canonicalised by the
@@ -124,6 +128,56 @@ int main(int argc, char **argv)
             if (!same(a, b)) {
                 bad++;
                 if (bad < 5) fprintf(stderr, "quant(%a,%a): pm=%a libm=%a\n", x, step, a, b);
+            }
+        }
+    } else if (!strcmp(mode, "acosbin")) {
+        uint64_t n = (1ull << 32) / arg;
+#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+        for (uint64_t i = 0; i < n; i++) {
+            const float c = PM_BITS_U2F((uint32_t)(i * arg));
+            const uint32_t b = pc_acos_bin(c, PC_ACOS_LUT);
+            const float a = acosf(c), q = a - fmodf(a, PM_D_ANGLE);
+            const int ok = b == 16u ? isnan(q) : (!isnan(q) && PM_BITS_F2U(q) == PM_BITS_F2U((float)b * PM_D_ANGLE));
+            checked++;
+            if (!ok) {
+                bad++;
+                if (bad < 5) fprintf(stderr, "acosbin(%a): table=%u libm quantised=%a\n", c, b, q);
+            }
+        }
+    } else if (!strcmp(mode, "pairbins")) {
+#pragma omp parallel for reduction(+ : bad, checked) schedule(static)
+        for (uint64_t i = 0; i < arg; i++) {
+            uint64_t s = i * 0x9e3779b97f4a7c15ull + 4242;
+            float v[12];
+            for (int j = 0; j < 12; j++) v[j] = (float)((double)(uint32_t)splitmix(&s) / 4294967296.0 * 2.0 - 1.0);
+            const uint64_t r = splitmix(&s);
+            /* the special cases the kernels meet: axis-aligned and parallel normals (acos arguments of exactly
+             * 0 and +-1), a zero normal, coincident points, a non-finite coordinate, lattice points */
+            switch (r % 16) {
+            case 0: v[3] = 0; v[4] = 0; v[5] = 1; v[9] = 0; v[10] = 0; v[11] = 1; break;
+            case 1: v[9] = v[3]; v[10] = v[4]; v[11] = v[5]; break;
+            case 2: v[9] = -v[3]; v[10] = -v[4]; v[11] = -v[5]; break;
+            case 3: v[3] = v[4] = v[5] = 0; break;
+            case 4: v[6] = v[0]; v[7] = v[1]; v[8] = v[2]; break;
+            case 5: v[(r >> 8) % 12] = (r >> 16) & 1 ? NAN : INFINITY; break;
+            case 6: for (int j = 0; j < 12; j++) v[j] = (float)(int)(v[j] * 4.0f) * 0.25f; break;
+            case 7: v[2] = v[8] = 0; v[3] = v[4] = v[9] = v[10] = 0; v[5] = v[11] = 1; break;
+            case 8: v[6] = v[0] + v[3]; v[7] = v[1] + v[4]; v[8] = v[2] + v[5]; break;
+            default: break;
+            }
+            const float d_dist = (r >> 24) % 3 == 0 ? 0.025f : (float)((double)(uint32_t)(r >> 32) / 4294967296.0 * 0.2 + 1e-3);
+            const float inv = 1.0f / d_dist;
+            const float n1n = pc_norm3(v[3], v[4], v[5]), n2n = pc_norm3(v[9], v[10], v[11]);
+            const uint32_t key = pc_pair_key(v[0], v[1], v[2], v[3], v[4], v[5], n1n, v[6], v[7], v[8], v[9], v[10], v[11], n2n, d_dist, inv);
+            uint32_t combo;
+            const int k1 = pc_pair_bins(v[0], v[1], v[2], v[3], v[4], v[5], n1n, v[6], v[7], v[8], v[9], v[10], v[11], n2n, d_dist, inv,
+                                        PC_ACOS_LUT, &combo);
+            checked++;
+            if (k1 < 0) continue;                 /* generic path: the kernels call pc_pair_key */
+            if (combo >= PC_ANGLE_COMBOS || pc_key_of_bins((uint32_t)k1, combo, d_dist) != key) {
+                bad++;
+                if (bad < 5) fprintf(stderr, "pairbins case %llu: key %08x, bins give %08x\n", (unsigned long long)i, key,
+                                     pc_key_of_bins((uint32_t)k1, combo, d_dist));
             }
         }
     } else if (!strcmp(mode, "alphabin") || !strcmp(mode, "hybrid")) {

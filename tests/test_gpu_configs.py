@@ -404,3 +404,32 @@ def test_counters_beyond_16_bits(ppf, oracle, built_lib, filler):
         assert mo.stats[k] == ost[k], k
     _, To = oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)
     assert np.array_equal(T, To)
+
+
+def test_distances_on_bin_edges(ppf, oracle, built_lib):
+    """The scene-key kernels find a pair's distance bin from the hardware's approximate square root and fall
+    back to the exact sequence near a bin edge.  Lattice clouds whose spacing IS d_dist (and a third and 1.5 times
+    d_dist) put most pair distances exactly on, one ulp below or one ulp above an edge: hit counts, peak cells and
+    pose equal the oracle's, so every such pair went to the reference's bin."""
+    rng = np.random.default_rng(11)
+    for h, mult in ((np.float32(0.05), 1.0), (np.float32(0.1), 1.0 / 3.0), (np.float32(0.037), 1.5)):
+        g = np.stack(np.meshgrid(np.arange(7), np.arange(7), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+        mp = (g[rng.permutation(len(g))[:150]] * h).astype(np.float32)
+        mn = rng.normal(size=(len(mp), 3)).astype(np.float32)
+        g2 = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(8), indexing="ij"), -1).reshape(-1, 3)
+        sp = (g2[rng.permutation(len(g2))[:900]] * h).astype(np.float32)
+        sn = rng.normal(size=(len(sp), 3)).astype(np.float32)
+        near = {tuple(v): i for i, v in enumerate(np.round(mp / h).astype(int))}
+        for j, v in enumerate(np.round(sp / h).astype(int) - 2):       # the model sits in the scene, shifted by 2 cells
+            if tuple(v) in near:
+                sn[j] = mn[near[tuple(v)]]
+        d = float(np.float32(h * np.float32(mult)))
+        sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=3)
+        mo = ppf.Model(mp, mn, d_dist=d)
+        T = mo.ppf_lookup(sc, allow_no_votes=True)
+        ocells, ost = oracle.votes_fused(mp, mn, sp, sn, 3, d, 0.4)
+        assert cells_equal(mo.last_cells()[0], ocells), float(h)
+        for key in ("num_scene_ppfs", "num_hits", "num_votes", "num_unique_votes", "max_count"):
+            assert mo.stats[key] == ost[key], (float(h), key)
+        if len(ocells):
+            assert np.array_equal(T, oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)[1])

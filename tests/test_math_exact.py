@@ -2,7 +2,8 @@
 
 pm_acosf and pm_atanf are compared with glibc on every one of the 2^32 floats; pm_atan2f,
 the exact quantisation, the alpha-bin threshold table and the quantised-angle scheme on
-hundreds of millions of structured and random inputs; the threshold table is re-derived
+hundreds of millions of structured and random inputs; the tabulated acos bins (pc_acos_bin) against the quantised
+libm acosf on every float, and the key rebuilt from a pair's bins against the hashed key on 3*10^8 pairs; the threshold table is re-derived
 from every ratio in [2^-63, 2^63].  These are the functions the GPU kernels run, so
 bit-exact PPF keys and reference-identical alpha bins rest on this file."""
 import os
@@ -26,7 +27,7 @@ def exe():
 
 @pytest.mark.parametrize("mode,arg", [("acosf", "1"), ("atanf", "1"), ("atan2f", "400000000"),
                                       ("quant", "200000000"), ("alphabin", "400000000"),
-                                      ("hybrid", "400000000")])
+                                      ("hybrid", "400000000"), ("acosbin", "1"), ("pairbins", "300000000")])
 def test_against_libm(exe, mode, arg):
     r = subprocess.run([exe, mode, arg], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
