@@ -40,8 +40,17 @@
 
 #define WAVE 64
 #define VOTE_THREADS 1024
-#define ACC_CELLS (OSLAMK_ROWS * OSLAMK_NBIN)
-#define ACC_REAL_CELLS (1023 * OSLAMK_NBIN)      /* counter words without the sink row; each holds two 16-bit counters */
+/* The accumulator of a vote workgroup in LDS: OSLAMK_ROWS rows of ACC_STRIDE words (bins 0..29 + one unused).
+ * The stride is odd on purpose: the LDS bank of a vote is (row * 31 + bin) mod 32 = (bin - row) mod 32, so votes
+ * of one instruction that fall into the same bin of different rows do not meet on a bank, and k_bucket_spread
+ * can order a bucket so that the 32 lanes the LDS serves together land on 32 different banks whatever the
+ * hit's angle is (a stride of 32 would make the bank the bin alone: 30 banks, and as crowded as the model's
+ * angles are). */
+#ifndef ACC_STRIDE
+#define ACC_STRIDE 31
+#endif
+#define ACC_CELLS (OSLAMK_ROWS * ACC_STRIDE)
+#define ACC_REAL_CELLS (1023 * ACC_STRIDE)       /* counter words without the sink row; each holds two 16-bit counters */
 
 /* thresholds of pc_alpha_bin_table(); every vote workgroup copies them into LDS */
 __device__ const uint32_t k_alpha_thr[32] = {PC_ALPHA_THR_FLAT};
@@ -268,17 +277,27 @@ __global__ void k_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, osl
     }
 }
 
-/* pass 3: order inside every bucket.  A vote instruction adds 64 lanes' entries into
- * acc[m_r][bin]; the LDS bank is the bin (rows are 32 words), and the bin is theta_v - theta_u, so
- * within one instruction the banks are as spread as the theta_u of the 32 lanes the LDS serves
- * together.  The fill pass leaves the entries in arrival order: 32 random angles on 30 banks
- * collide 3-4 deep (7 LDS cycles per instruction instead of 4, tools/micro/lds_atomic_bench.hip).
- * Here every segment of 4096 positions (16 chunks) of a bucket is sorted by theta_u and dealt out
- * so that each such group of 32 (same chunk, same register j, same half of the wave) takes every
- * G-th entry of the sorted order: evenly spaced angles, mostly distinct banks.  Votes commute, so
- * the order inside a bucket is free (model.cu:95-171 sorts them anyway).  One workgroup per slot. */
+/* pass 3: order inside every bucket.  A vote instruction adds 64 lanes' entries into acc[row][bin]; the LDS
+ * serves 32 lanes together, one cycle per distinct address on the busiest bank (two are free: the instruction
+ * takes four cycles to hand over its operands anyway).  The fill pass leaves the entries in arrival order:
+ * 32 random banks collide 3-4 deep (7 LDS cycles per instruction instead of 4, tools/micro/lds_atomic_bench.hip).
+ * Here every segment of 4096 positions (16 chunks) of a bucket is sorted by spread_key -- the quantity that
+ * decides an entry's bank for every hit angle at once -- and dealt out so that each such group of 32 (same
+ * chunk, same register j, same half of the wave) takes every G-th entry of the sorted order: keys about one
+ * bank apart, mostly distinct banks.  Votes commute, so the order inside a bucket is free (model.cu:95-171
+ * sorts them anyway).  One workgroup per slot. */
 #define SPREAD_SEG 4096
 #define SPREAD_THREADS 256
+/* What the entries of a bucket are ordered by: the bank a vote lands on is floor(s - kappa) mod 32 with
+ * kappa = (theta_u in bins - ACC_STRIDE * row) mod 32 and s the hit's angle in bins (but for the wrap of the bin
+ * at 30, which moves a bank by 2), so lanes whose kappa are one apart never collide, whatever s is.  In units
+ * of 2^-16 bank. */
+__device__ __forceinline__ uint32_t spread_key(uint32_t entry_word)
+{
+    const uint32_t u = ((entry_word >> PC_ROW_BITS) * 30u) >> 5;              /* theta_u21 * 30 / 2^21 bins, << 16 */
+    const uint32_t row = entry_word & PC_ROW10_MASK;
+    return (u - ((row * ACC_STRIDE) << 16)) & ((32u << 16) - 1u);
+}
 /* how many positions p' < n of a chunk image (position = 4*lane + j) come before position p in
  * the dealing order (lane & 31, j, lane >> 5), for a chunk that holds n entries */
 __device__ __forceinline__ uint32_t spread_rank_in_chunk(uint32_t p, uint32_t n)
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_bucket_spread(oslamk_table t
                 s_e4[i] = w;
                 if (ent.uv) s_uv[i] = ent.uv[base + i];
                 s_mi[i] = ent.mi[base + i];
-                key[i] = ((unsigned long long)(w >> PC_ROW_BITS) << 32) | i;
+                key[i] = ((unsigned long long)spread_key(w) << 32) | i;
             } else {
                 key[i] = ~0ull;
             }
@@ -449,7 +468,7 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
             const float vy = pc_row_dot(sc->rows, x, y, z);        /* as k_scene_hits computed them */
             const float vz = pc_row_dot(sc->rows + 4, x, y, z);
             const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
-            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[(mr << 5) + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
+            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
             else atomicAdd((uint32_t *)&sc->dropped, 1u);
         }
     }
@@ -534,7 +553,7 @@ struct VoteRegs {
         uint32_t rowb[4], inc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            rowb[j] = acc_base + ((wa[j] & PC_ROW10_MASK) << 7);     /* LDS address of the entry's row */
+            rowb[j] = acc_base + (wa[j] & PC_ROW10_MASK) * (4u * ACC_STRIDE);     /* LDS address of the entry's row */
             inc[j] = (wa[j] >> PC_ROW_HALF_BIT) & 1u ? inc_hi : inc_lo;
         }
         /* lanes that hold at least one entry of this chunk */
@@ -1347,8 +1366,13 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
     #pragma unroll 2
         for (int c = tid; c < ACC_REAL_CELLS; c += VOTE_THREADS) {
                 const uint32_t w = acc[c];
-                if (pass <= 1) dst[c] = lower_of(w);
-                if (pass != 1) dst[c + ACC_REAL_CELLS] = upper_of(w);
+                const int cell = c / ACC_STRIDE * OSLAMK_NBIN + c % ACC_STRIDE;
+                if (pass <= 1) dst[cell] = lower_of(w);
+                if (pass != 1) dst[cell + (int)PC_ROWS_PER_HALF * OSLAMK_NBIN] = upper_of(w);
+                if (ACC_STRIDE < OSLAMK_NBIN && c % ACC_STRIDE == ACC_STRIDE - 1) {      /* the dump's last column */
+                    if (pass <= 1) dst[cell + 1] = 0;
+                    if (pass != 1) dst[cell + 1 + (int)PC_ROWS_PER_HALF * OSLAMK_NBIN] = 0;
+                }
             }
         }
 
@@ -1390,9 +1414,9 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
                     if ((float)v > bound) {
                         if (pos < a.out_cap) {
                             oslamk_cell cell;
-                            const uint32_t m_r = m_base + (uint32_t)hf * PC_ROWS_PER_HALF + (uint32_t)(c / OSLAMK_NBIN);
+                            const uint32_t m_r = m_base + (uint32_t)hf * PC_ROWS_PER_HALF + (uint32_t)(c / ACC_STRIDE);
                             cell.code = ((unsigned long long)r << 32) | (unsigned long long)((m_r << 6) |
-                                                                         (uint32_t)(c % OSLAMK_NBIN));
+                                                                         (uint32_t)(c % ACC_STRIDE));
                             cell.count = v;
                             cell.pad = 0;
                             a.out[pos] = cell;
