@@ -452,6 +452,7 @@ typedef __attribute__((address_space(3))) SlowCtx lds_ctx;
  * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
  * a time by slow_queue_flush().  q: the wave's SLOW_CAP places; n: how many are taken (wave-uniform). */
 #define SLOW_CAP 96
+#define SLOW_VERIFY 0x80000000u        /* in an item's entry index: the four votes entry .. entry+3 of the hit have been cast */
 
 __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n, int lane)
 {
@@ -459,17 +460,44 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
     for (uint32_t base = 0; base < n; base += WAVE) {
         if (base + lane < n) {
             const unsigned long long it = q[base + lane];
-            const uint32_t entry = (uint32_t)it;
-            const uint32_t ew = sc->e4[entry];
-            const uint32_t mr = ew & PC_ROW10_MASK;
-            const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
-            const uint32_t i = sc->hits[(uint32_t)(it >> 32)].idx;
+            const uint32_t entry = (uint32_t)it & ~SLOW_VERIFY;
+            const oslamk_pay hp = sc->hits[(uint32_t)(it >> 32)];
+            const uint32_t i = hp.idx;
             const float x = sc->px[i], y = sc->py[i], z = sc->pz[i];
             const float vy = pc_row_dot(sc->rows, x, y, z);        /* as k_scene_hits computed them */
             const float vz = pc_row_dot(sc->rows + 4, x, y, z);
-            const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
-            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
-            else atomicAdd((uint32_t *)&sc->dropped, 1u);
+            if (!((uint32_t)it & SLOW_VERIFY)) {
+                /* a vote that has not been cast (an item with a marker) */
+                const uint32_t ew = sc->e4[entry];
+                const uint32_t mr = ew & PC_ROW10_MASK;
+                const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
+                const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
+                if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
+                else atomicAdd((uint32_t *)&sc->dropped, 1u);
+            } else {
+                /* four votes that have been cast, at least one of them within the margin of a bin edge: those are
+                 * evaluated with the reference's float sequence and moved if the quantised bin was not the
+                 * reference's (a counter word is only ever added to and subtracted from, so a carry between its two
+                 * halves that the misplaced vote caused is undone with it) */
+                const uint32_t csm = pc_vote_base_t32(hp.theta_t22);
+#pragma nounroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t ew = sc->e4[entry + j];
+                    const uint32_t mr = ew & PC_ROW10_MASK;
+                    uint32_t qbin, pos;
+                    vote_product(csm - ew, qbin, pos);
+                    if (mr != PC_ROW_SINK && pos < PC_T24_EDGE) {
+                        const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry + j]);
+                        const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
+                        if (bin != qbin) {
+                            const uint32_t inc = (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo;
+                            atomicSub((uint32_t *)&acc[mr * ACC_STRIDE + qbin], inc);
+                            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], inc);
+                            else atomicAdd((uint32_t *)&sc->dropped, 1u);
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -549,12 +577,16 @@ struct VoteRegs {
         const uint32_t wa[4] = {v.x, v.y, v.z, v.w};
         const uint32_t csmv = pc_vote_base_t32(th);
         const uint32_t acc_base = (uint32_t)(uintptr_t)acc;  /* the accumulator's LDS address */
-        const uint32_t trash_addr = acc_base + 4u * (ACC_TRASH + (uint32_t)lane);
         uint32_t rowb[4], inc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             rowb[j] = acc_base + (wa[j] & PC_ROW10_MASK) * (4u * ACC_STRIDE);     /* LDS address of the entry's row */
-            inc[j] = (wa[j] >> PC_ROW_HALF_BIT) & 1u ? inc_hi : inc_lo;
+            /* inc_lo or inc_hi by the half bit: a bit-field extract and (first pass) one 24-bit multiply-add, in asm
+             * because the compiler turns every spelling of it into and + compare + select */
+            if (inc_hi == 0x10000u)
+                asm("v_bfe_u32 %0, %1, 10, 1\n\tv_mad_u32_u24 %0, %0, %2, 1" : "=&v"(inc[j]) : "v"(wa[j]), "s"(0xffffu));
+            else
+                inc[j] = (wa[j] >> PC_ROW_HALF_BIT) & 1u ? inc_hi : inc_lo;
         }
         /* lanes that hold at least one entry of this chunk */
         const unsigned long long live = __ballot(4u * (uint32_t)lane < d.left);
@@ -572,30 +604,17 @@ struct VoteRegs {
                 addr[j] = rowb[j] + (bin << 2);
             }
             if (MODE == 0) {
-                /* position inside the (shifted) bin, in 2^-32 bin: below PC_T24_EDGE = within the margin
-                 * of an edge.  One compare of the smallest of the four decides whether anything is
-                 * queued; lanes past the bucket end only ever cause a look that finds nothing. */
+                /* position inside the (shifted) bin, in 2^-32 bin: below PC_T24_EDGE = within the margin of an
+                 * edge.  One compare of the smallest of the four finds the lanes that have such a vote; their
+                 * four votes are cast like all others and noted in the wave's queue, whose flush looks at them again
+                 * and moves the ones that the reference's float sequence puts into the other bin (one vote in 2000
+                 * is near an edge, one in eight of those moves).  Lanes past the bucket end cast nothing. */
                 const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
-                if (__builtin_expect(__any(min(lo3, pos[3]) < PC_T24_EDGE), 0)) {
-                    /* queued for re-evaluation, their lanes redirected to the trash word.  One rolled loop
-                     * over the four entries of a lane: this block is cold and exists once per copy of the
-                     * vote loop, with the queue's flush inlined (a call would make the register allocator
-                     * spill around the whole loop) */
+                const unsigned long long near = __ballot(min(lo3, pos[3]) < PC_T24_EDGE) & live;
+                if (__builtin_expect(near != 0ull, 0)) {
                     uint32_t e = 4u * (uint32_t)lane;
-                    asm volatile("" : "+v"(e));
-#pragma nounroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t pj = j == 0 ? pos[0] : j == 1 ? pos[1] : j == 2 ? pos[2] : pos[3];
-                        const unsigned long long nm = __ballot(e + (uint32_t)j < d.left && pj < PC_T24_EDGE);
-                        if (nm) {
-                            qn = slow_push(sc, acc, tbl, q, qn, nm, d.e0 + e + (uint32_t)j, d.h0 + i, lane);
-                            const bool me = (nm >> lane) & 1ull;
-                            addr[0] = me && j == 0 ? trash_addr : addr[0];
-                            addr[1] = me && j == 1 ? trash_addr : addr[1];
-                            addr[2] = me && j == 2 ? trash_addr : addr[2];
-                            addr[3] = me && j == 3 ? trash_addr : addr[3];
-                        }
-                    }
+                    asm volatile("" : "+v"(e));          /* keeps the item's arithmetic on the cold side of the branch */
+                    qn = slow_push(sc, acc, tbl, q, qn, near, (d.e0 + e) | SLOW_VERIFY, d.h0 + i, lane);
                 }
             }
 #ifdef VOTE_DIAG_NOATOM             /* timing-only build: the vote arithmetic without the LDS atomics */
