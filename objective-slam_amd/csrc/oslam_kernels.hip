@@ -519,7 +519,7 @@ __device__ __forceinline__ uint32_t slow_push(lds_ctx *sc, lds_u32 *acc, lds_u32
  * i0 .. i1-1 of a run (at most 64 hits, one per lane). */
 struct VoteStep {
     uint32_t e0;                       /* index of the chunk's first entry */
-    uint32_t left;                     /* entries from the chunk start to the bucket end (>= 1) */
+    uint32_t left;                     /* entries from the chunk start to the bucket end (>= 1), capped at 256 */
     uint32_t h0;                       /* index of the run's first hit in the reference point's sorted list */
     uint32_t R;                        /* hits of the run */
     uint32_t i0, i1;                   /* the hits of the run that vote in this step */
@@ -558,9 +558,12 @@ struct VoteRegs {
      * (vmcnt(N)) instead of draining everything. */
     __device__ __forceinline__ void load(const uint32_t *e4, const oslamk_pay *hits, const VoteStep &d, int lane)
     {
-        /* lanes past the end of the bucket / the run re-read its first bytes (no extra traffic) */
-        v = reinterpret_cast<const uint4 *>(e4 + d.e0)[4u * (uint32_t)lane < d.left ? lane : 0];
-        th = hits[d.h0 + ((uint32_t)lane < d.R ? (uint32_t)lane : 0u)].theta_t22;
+        /* lanes past the end of the bucket / the run re-read its first bytes (no extra traffic); wave-uniform base
+         * + 32-bit lane offset, so that the address costs one select per load */
+        const uint32_t lane16 = 16u * (uint32_t)lane, lane8 = 8u * (uint32_t)lane;
+        v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(e4 + d.e0) + (4u * (uint32_t)lane < d.left ? lane16 : 0u));
+        th = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(&hits[d.h0].theta_t22) +
+                                                 ((uint32_t)lane < d.R ? lane8 : 0u));
     }
     /* returns the length of the wave's re-evaluation queue */
     __device__ __forceinline__ uint32_t vote(const SlowCtx *scp, uint32_t *accp, const uint32_t *tblp, unsigned long long *qp,
@@ -1139,15 +1142,15 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
         };
         /* step g of a window: its descriptor from lane g of the window's registers (VOTE_GROUP divides 64, so a
          * group never runs past lane 63; lanes past the window's end describe empty steps) */
-        auto step_at = [&](uint32_t ve0, uint32_t vleft, uint32_t vh0, uint32_t vmisc, int l) -> VoteStep {
+        auto step_at = [&](uint32_t ve0, uint32_t vh0, uint32_t vmisc, int l) -> VoteStep {
             VoteStep d;
             const uint32_t misc = readlane_u(vmisc, l);
             d.e0 = readlane_u(ve0, l);
-            d.left = readlane_u(vleft, l);
             d.h0 = readlane_u(vh0, l);
             d.R = (misc & 63u) + 1u;
             d.i0 = (misc >> 6) & 127u;
             d.i1 = (misc >> 13) & 127u;
+            d.left = misc >> 20;            /* capped at a chunk: all a step asks is which lanes hold entries */
             d.valid = true;
             return d;
         };
@@ -1181,15 +1184,16 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
                 const uint32_t c = local >> lg, hs = local & ((1u << lg) - 1u), per = (R + (1u << lg) - 1u) >> lg;
                 const uint32_t i0 = hs * per, i1 = i0 + per < R ? i0 + per : R;
                 /* a lane past the end describes a step that loads entry 0 and hit 0 and votes nothing */
-                const uint32_t w_e0 = act ? st + (c << 8) : 0u, w_left = act ? ln - (c << 8) : 0u, w_h0 = act ? h0 : 0u,
-                               w_misc = act ? (R - 1u) | (i0 << 6) | (i1 << 13) : 0u;
+                const uint32_t left = ln - (c << 8);
+                const uint32_t w_e0 = act ? st + (c << 8) : 0u, w_h0 = act ? h0 : 0u,
+                               w_misc = act ? (R - 1u) | (i0 << 6) | (i1 << 13) | ((left < 256u ? left : 256u) << 20) : 0u;
                 const uint32_t rest = (total - ub + stride - 1u) / stride, n_w = rest < (uint32_t)WAVE ? rest : (uint32_t)WAVE;
                 for (uint32_t g0 = 0; g0 < n_w; g0 += VOTE_GROUP) {
                     VR regs[VOTE_GROUP];
                     VoteStep ds[VOTE_GROUP];
     #pragma unroll
                     for (int g = 0; g < VOTE_GROUP; g++) {
-                        ds[g] = step_at(w_e0, w_left, w_h0, w_misc, (int)g0 + g);
+                        ds[g] = step_at(w_e0, w_h0, w_misc, (int)g0 + g);
                         regs[g].load(e4, hits, ds[g], lane);
                     }
                     asm volatile("" ::: "memory");      /* all the group's loads are issued here, in this order: none sinks into its vote */
