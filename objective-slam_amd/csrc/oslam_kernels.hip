@@ -39,7 +39,9 @@
 #include "ppf_core.h"
 
 #define WAVE 64
+#ifndef VOTE_THREADS
 #define VOTE_THREADS 1024
+#endif
 /* The accumulator of a vote workgroup in LDS: OSLAMK_ROWS rows of ACC_STRIDE words (bins 0..29 + one unused).
  * The stride is odd on purpose: the LDS bank of a vote is (row * 31 + bin) mod 32 = (bin - row) mod 32, so votes
  * of one instruction that fall into the same bin of different rows do not meet on a bank, and k_bucket_spread
