@@ -445,6 +445,24 @@ struct SlowCtx {
     uint32_t dropped;                  /* re-evaluated votes that fell into no bin (alpha not a number) */
 };
 
+/* The second instantiation of ppf_math_atan.inc (see there): pm_atan2f_cold / pc_alpha_bin_exact_cold with every
+ * literal materialised where it is used.  The re-evaluation of a vote takes the table path (pc_alpha_bin_table_main)
+ * and this formula only for inputs the table does not cover -- zero or non-finite cross and dot products. */
+#define PM_FN(n) n##_cold
+#define PM_KU(bits) ({ uint32_t pinned_; asm volatile("v_mov_b32 %0, %1" : "=v"(pinned_) : "i"(bits)); pinned_; })
+#define PM_KF(bits) __builtin_bit_cast(float, PM_KU(bits))
+#undef PM_HD
+#define PM_HD __device__ static inline
+#include "ppf_math_atan.inc"
+#undef PM_FN
+#undef PM_KU
+#undef PM_KF
+__device__ __forceinline__ unsigned alpha_bin_reeval(float uy, float uz, float vy, float vz, const uint32_t *tbl)
+{
+    const unsigned b = pc_alpha_bin_table_main(uy, uz, vy, vz, tbl);
+    return b != PC_ALPHA_OUTSIDE ? b : pc_alpha_bin_exact_cold(uy, uz, vy, vz);
+}
+
 /* LDS pointers of the out-of-line paths; their context lives in LDS too (a kernel's stack would be scratch memory) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
@@ -473,7 +491,7 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
                 const uint32_t ew = sc->e4[entry];
                 const uint32_t mr = ew & PC_ROW10_MASK;
                 const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
-                const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
+                const unsigned bin = alpha_bin_reeval(uv.x, uv.y, vy, vz, t);
                 if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
                 else atomicAdd((uint32_t *)&sc->dropped, 1u);
             } else {
@@ -490,7 +508,7 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
                     vote_product(csm - ew, qbin, pos);
                     if (mr != PC_ROW_SINK && pos < PC_T24_EDGE) {
                         const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry + j]);
-                        const unsigned bin = pc_alpha_bin_table(uv.x, uv.y, vy, vz, t);
+                        const unsigned bin = alpha_bin_reeval(uv.x, uv.y, vy, vz, t);
                         if (bin != qbin) {
                             const uint32_t inc = (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo;
                             atomicSub((uint32_t *)&acc[mr * ACC_STRIDE + qbin], inc);
@@ -563,7 +581,7 @@ struct VoteRegs {
         /* lanes past the end of the bucket / the run re-read its first bytes (no extra traffic); wave-uniform base
          * + 32-bit lane offset, so that the address costs one select per load */
         const uint32_t lane16 = 16u * (uint32_t)lane, lane8 = 8u * (uint32_t)lane;
-        v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(e4 + d.e0) + (4u * (uint32_t)lane < d.left ? lane16 : 0u));
+        v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(e4 + d.e0) + ((uint32_t)lane < (d.left + 3u) >> 2 ? lane16 : 0u));
         th = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(&hits[d.h0].theta_t22) +
                                                  ((uint32_t)lane < d.R ? lane8 : 0u));
     }
@@ -580,7 +598,10 @@ struct VoteRegs {
          * those of the upper half 0x10000 (inc_lo / inc_hi; one of them is 0 in the rare second and third pass
          * of a workgroup whose 16-bit counters overflowed) */
         const uint32_t wa[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t csmv = pc_vote_base_t32(th);
+        /* pc_vote_base_t32(th) = (th << 10) + a constant, which is kept in a scalar register (the compiler would
+         * park it in a vector register that exact mode does not have to spare) */
+        uint32_t csmv;
+        asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(csmv) : "v"(th), "s"(pc_vote_base_t32(0u)));
         const uint32_t acc_base = (uint32_t)(uintptr_t)acc;  /* the accumulator's LDS address */
         uint32_t rowb[4], inc[4];
 #pragma unroll
@@ -594,7 +615,7 @@ struct VoteRegs {
                 inc[j] = (wa[j] >> PC_ROW_HALF_BIT) & 1u ? inc_hi : inc_lo;
         }
         /* lanes that hold at least one entry of this chunk */
-        const unsigned long long live = __ballot(4u * (uint32_t)lane < d.left);
+        const unsigned long long live = __ballot((uint32_t)lane < (d.left + 3u) >> 2);
 #ifdef VOTE_DIAG_NOLOOP                 /* timing-only build: steps and loads without the votes */
         asm volatile("" ::"v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(csmv), "s"(live));
         return qn;

@@ -123,19 +123,7 @@ PM_HD float pc_row_dot(const float *row, float px, float py, float pz)
     return row[0] * px + row[1] * py + row[2] * pz + row[3] * 1.0f;
 }
 
-/* alpha bin of kernel.cu:338-342 from u = (0,uy,uz), v = (0,vy,vz):
- * alpha = atan2f(cross(u,v).x, dot(u,v)); quant_downf(alpha + pi, D) / D.
- * Returns 0..30, or 255 when alpha is NaN. */
-PM_HD unsigned pc_alpha_bin_exact(float uy, float uz, float vy, float vz)
-{
-    float cx = uy * vz - uz * vy;                 /* kernel.cu:84 */
-    float dt = 0.0f * 0.0f + uy * vy + uz * vz;   /* kernel.cu:52 with u.x = v.x = 0 */
-    float alpha = pm_atan2f(cx, dt) + PM_PI_F;
-    int k;
-    (void)pm_quant_down_pos(alpha, PM_D_ANGLE, 1.0f / PM_D_ANGLE, &k);
-    /* lrintf(RN(k*D)/D) == k for k <= 31: |RN(k*D)/D - k| <= 31*2^-23 */
-    return ((unsigned)k > 31u) ? 255u : (unsigned)k;
-}
+/* pc_alpha_bin_exact (alpha bin of kernel.cu:338-342 by the full formula): ppf_math_atan.inc */
 
 /* The same bin without evaluating atan2f: in atan2f's main path the result is a
  * function of q = fl(|cross/dot|) and the two signs only, and the bin is a monotone
@@ -144,7 +132,8 @@ PM_HD unsigned pc_alpha_bin_exact(float uy, float uz, float vy, float vz)
  * table PC_ALPHA_THR (32 words; the kernels keep a copy in LDS, one word per bank).
  * Inputs outside the main path (zero, infinite, NaN or 2^60 apart) take the full
  * formula. */
-PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const uint32_t *tbl)
+#define PC_ALPHA_OUTSIDE 0xffffffffu      /* pc_alpha_bin_table_main: the input is outside the main path */
+PM_HD unsigned pc_alpha_bin_table_main(float uy, float uz, float vy, float vz, const uint32_t *tbl)
 {
     const float cx = uy * vz - uz * vy;
     const float dt = 0.0f * 0.0f + uy * vy + uz * vz;
@@ -164,7 +153,12 @@ PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const 
         /* PC_ALPHA_BASE = {15, 15, 30, 0}; + for quadrants 0 and 3, - for 1 and 2 */
         return (m == 0u) ? 15u + pos : (m == 1u) ? 15u - pos : (m == 2u) ? 30u - pos : pos;
     }
-    return pc_alpha_bin_exact(uy, uz, vy, vz);
+    return PC_ALPHA_OUTSIDE;
+}
+PM_HD unsigned pc_alpha_bin_table(float uy, float uz, float vy, float vz, const uint32_t *tbl)
+{
+    const unsigned b = pc_alpha_bin_table_main(uy, uz, vy, vz, tbl);
+    return b != PC_ALPHA_OUTSIDE ? b : pc_alpha_bin_exact(uy, uz, vy, vz);
 }
 
 /* ---- quantised-angle voting -------------------------------------------------

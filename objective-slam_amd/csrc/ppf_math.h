@@ -96,88 +96,11 @@ PM_HD float pm_acosf(float x)
     return res;
 }
 
-/* atanf of a non-negative finite-or-inf argument, fdlibm s_atanf.c: the four
- * argument reductions are one division num/den with per-range coefficients
- * (num = a*x + b, den = c*x + d; a*x and c*x round exactly as fdlibm's terms). */
-PM_HD float pm_atanf_pos_(float ax)
-{
-    const float aT0 = PM_BITS_U2F(0x3eaaaaabu), aT1 = PM_BITS_U2F(0xbe4ccccdu),
-                aT2 = PM_BITS_U2F(0x3e124925u), aT3 = PM_BITS_U2F(0xbde38e38u),
-                aT4 = PM_BITS_U2F(0x3dba2e6eu), aT5 = PM_BITS_U2F(0xbd9d8795u),
-                aT6 = PM_BITS_U2F(0x3d886b35u), aT7 = PM_BITS_U2F(0xbd6ef16bu),
-                aT8 = PM_BITS_U2F(0x3d4bda59u), aT9 = PM_BITS_U2F(0xbd15a221u),
-                aT10 = PM_BITS_U2F(0x3c8569d7u);
-    const uint32_t ix = PM_BITS_F2U(ax);
-    /* range id: -1: <7/16, 0: <11/16, 1: <19/16, 2: <39/16, 3: above */
-    const int r0 = ix >= 0x3ee00000u, r1 = ix >= 0x3f300000u, r2 = ix >= 0x3f980000u,
-              r3 = ix >= 0x401c0000u;
-    const float a = r3 ? 0.0f : ((r0 && !r1) ? 2.0f : 1.0f);
-    const float b = r3 ? -1.0f : (r2 ? -1.5f : (r0 ? -1.0f : 0.0f));
-    const float c = r3 ? 1.0f : (r2 ? 1.5f : (r0 ? 1.0f : 0.0f));
-    const float d = r3 ? 0.0f : (r2 ? 1.0f : (r1 ? 1.0f : (r0 ? 2.0f : 1.0f)));
-    const float hi = PM_BITS_U2F(r3 ? 0x3fc90fdau : (r2 ? 0x3f7b985eu : (r1 ? 0x3f490fdau : (r0 ? 0x3eed6338u : 0u))));
-    const float lo = PM_BITS_U2F(r3 ? 0x33a22168u : (r2 ? 0x33140fb4u : (r1 ? 0x33222168u : (r0 ? 0x31ac3769u : 0u))));
-    const float xr = (a * ax + b) / (c * ax + d);
-    const float z = xr * xr;
-    const float w = z * z;
-    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
-    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    /* with hi = lo = 0 this is x - x*(s1+s2), the |x| < 7/16 form */
-    float res = hi - ((xr * (s1 + s2) - lo) - xr);
-    if (ix < 0x31000000u) res = ax;                                    /* |x| < 2^-29 */
-    if (ix >= 0x4c000000u) res = PM_BITS_U2F(0x3fc90fdau) + PM_BITS_U2F(0x33a22168u);   /* |x| >= 2^25 */
-    return res;
-}
-
-PM_HD float pm_atanf(float x)
-{
-    const uint32_t hx = PM_BITS_F2U(x);
-    const uint32_t ix = hx & 0x7fffffffu;
-    float r;
-    if (ix > 0x7f800000u) return x + x;
-    r = pm_atanf_pos_(PM_BITS_U2F(ix));
-    return PM_BITS_U2F(PM_BITS_F2U(r) | (hx & 0x80000000u));
-}
-
-/* atan2f: fdlibm e_atan2f.c algorithm (atanf(|y/x|), quadrant fix-up with a
- * split pi, then the special cases as overriding selects). */
-PM_HD float pm_atan2f(float y, float x)
-{
-    const float tiny = PM_BITS_U2F(0x0da24260u);
-    const float pi_o_4 = PM_BITS_U2F(0x3f490fdbu);
-    const float pi_o_2 = PM_BITS_U2F(0x3fc90fdbu);
-    const float pi = PM_BITS_U2F(0x40490fdbu);
-    const float pi_lo = PM_BITS_U2F(0xb3bbbd2eu);
-    const uint32_t hx = PM_BITS_F2U(x), hy = PM_BITS_F2U(y);
-    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
-    const int xneg = (int)(hx >> 31), yneg = (int)(hy >> 31);
-    const int k = ((int32_t)iy - (int32_t)ix) >> 23;
-    const float z0 = pm_atanf_pos_(pm_fabsf(y / x));
-    float z = z0, res;
-    if (xneg && k < -60) z = 0.0f;
-    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
-    {
-        const float zl = z - pi_lo;
-        const float r01 = PM_BITS_U2F(PM_BITS_F2U(z) ^ ((uint32_t)yneg << 31));
-        const float r23 = yneg ? zl - pi : pi - zl;
-        res = xneg ? r23 : r01;
-    }
-    if (iy == 0x7f800000u) res = yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;
-    if (ix == 0x7f800000u) {
-        if (iy == 0x7f800000u) {
-            const float q1 = pi_o_4 + tiny, q3 = 3.0f * pi_o_4 + tiny;
-            res = xneg ? (yneg ? -3.0f * pi_o_4 - tiny : q3) : (yneg ? -pi_o_4 - tiny : q1);
-        } else {
-            res = xneg ? (yneg ? -pi - tiny : pi + tiny) : (yneg ? -0.0f : 0.0f);
-        }
-    }
-    if (ix == 0) res = yneg ? -pi_o_2 - tiny : pi_o_2 + tiny;
-    if (iy == 0) res = xneg ? (yneg ? -pi - tiny : pi + tiny) : y;
-    if (hx == 0x3f800000u) res = PM_BITS_U2F(PM_BITS_F2U(z0) | (hy & 0x80000000u));   /* atanf(y) */
-    if (ix > 0x7f800000u || iy > 0x7f800000u) res = x + y;
-    return res;
-}
-
+/* pm_atanf_pos_, pm_atanf, pm_atan2f and pc_alpha_bin_exact: ppf_math_atan.inc (see there for why it is a
+ * separate text) */
+#define PM_FN(n) n
+#define PM_KF(bits) PM_BITS_U2F(bits)
+#define PM_KU(bits) (bits)
 /* Exact x - fmodf(x, step) for x >= 0 (or NaN), step > 0:
  * fmodf is exact, so the reference's quant_downf (kernel.cu:90-92) equals
  * RN(k * step) with k = floor(x / step) in exact arithmetic.  k is found with
@@ -198,6 +121,11 @@ PM_HD float pm_quant_down_pos(float x, float step, float inv_step, int *k_out)
     *k_out = (int)kf;
     return kf * step;
 }
+
+#include "ppf_math_atan.inc"
+#undef PM_FN
+#undef PM_KF
+#undef PM_KU
 
 /* 32-bit FNV-1a over raw bytes read through a SIGNED char, as the reference's
  * hash() does (kernel.cu:23-30; offset basis kernel.h:22): bytes >= 0x80 are
