@@ -210,10 +210,13 @@ def main():
         votes_per_s_kernel = st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3)
         # ceilings of the vote loop (tools/micro/): one conflict-free ds_add_u32 wave-instruction
         # (64 votes) per 4.4 cycles per CU (measured); one hit voting with a chunk = 256 votes = 16 vector
-        # instructions in exact mode, 13 in fast mode, 4 cycles each on one of 1024 SIMDs; 2.4 GHz
+        # instructions in exact mode, 13 in fast mode, at their measured issue costs (v_sub_u32 2.33 cycles per
+        # wave-instruction, everything else in the loop 4.2-4.3: tools/micro/valu_rate_bench.hip) on one of 1024
+        # SIMDs; 2.4 GHz
         lds_peak = 256 * 64 * 2.4e9 / 4.4
         valu_instr = 16 if mode == 0 else 13
-        valu_peak = 1024 * 256 * 2.4e9 / (4.0 * valu_instr)
+        valu_cycles = 60.5 if mode == 0 else 47.5
+        valu_peak = 1024 * 256 * 2.4e9 / valu_cycles
         dt, dr = ppf.ht_dist(T, poses[0][1])
         traffic, traffic_note = pmc_traffic(args, M, S, df)
         out = {
@@ -262,8 +265,9 @@ def main():
                          "torch_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps},
             "roofline_valu": {"bound": "valu_issue", "kernel": "k_vote", "unit": "votes/s", "achieved": votes_per_s_kernel,
                               "peak": valu_peak, "frac": votes_per_s_kernel / valu_peak,
-                              "note": "votes per second of vote-kernel time against 256 votes per %d vector instructions "
-                                      "(one vote iteration of the inner loop, nothing else) at 4 cycles each" % valu_instr},
+                              "note": "votes per second of vote-kernel time against 256 votes per %d vector instructions = "
+                                      "%.1f SIMD cycles at their measured issue costs (one vote iteration of the inner "
+                                      "loop, nothing else)" % (valu_instr, valu_cycles)},
             "roofline_lds_atomic": {"bound": "lds_atomic", "kernel": "k_vote", "unit": "votes/s",
                                     "achieved": votes_per_s_kernel, "peak": lds_peak, "frac": votes_per_s_kernel / lds_peak,
                                     "note": "against the measured conflict-free ds_add_u32 rate of the chip"},
