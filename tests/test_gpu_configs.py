@@ -433,3 +433,31 @@ def test_distances_on_bin_edges(ppf, oracle, built_lib):
             assert mo.stats[key] == ost[key], (float(h), key)
         if len(ocells):
             assert np.array_equal(T, oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)[1])
+
+
+@pytest.mark.parametrize("bins", [3000, 40000])
+def test_more_distance_bins_than_the_key_map_covers(ppf, oracle, built_lib, bins):
+    """The scene-key kernel looks a pair up in the key map for distance bins below 2048 and hashes and probes beyond
+    it; beyond 16384 bins the reach bitset ends and every pair is keyed.  A d_dist so small that the clouds span
+    3000 (40000) bins exercises both seams: counters, peak cells and pose equal the oracle's."""
+    rng = np.random.default_rng(77)
+    M, S = 90, 260
+    mp = rng.uniform(-1, 1, (M, 3)).astype(np.float32)
+    mn = rng.normal(size=(M, 3)).astype(np.float32)
+    R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    sp = rng.uniform(-2, 2, (S, 3)).astype(np.float32)
+    sn = rng.normal(size=(S, 3)).astype(np.float32)
+    sp[:M] = (mp @ R.T + np.float32([0.3, -0.2, 0.1])).astype(np.float32)
+    sn[:M] = (mn @ R.T).astype(np.float32)
+    d = float(np.float32(7.0 / bins))
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=1)
+    mo = ppf.Model(mp, mn, d_dist=d)
+    for r in (0, 5, M - 1):
+        assert np.array_equal(sc.getHashKeys(r), oracle.ppf_row_keys(sp, sn, r, d))
+    T = mo.ppf_lookup(sc, allow_no_votes=True)
+    ocells, ost = oracle.votes_fused(mp, mn, sp, sn, 1, d, 0.4)
+    assert cells_equal(mo.last_cells()[0], ocells)
+    for key in ("num_scene_ppfs", "num_hits", "num_votes", "num_unique_votes", "max_count"):
+        assert mo.stats[key] == ost[key], key
+    if len(ocells):
+        assert np.array_equal(T, oracle.pose_from_cells(ocells, mp, mn, sp, sn, d)[1])
