@@ -80,3 +80,92 @@ if __name__ == "__main__":
         res[name] = c
         print("%-14s array cycles/instr %.3f   max(4,.) %.3f   share >4: %.3f  lens median %d" % (
             name, c.mean(), np.maximum(c, 4).mean(), (c > 4).mean(), np.median(lens[pick])))
+
+
+def spread_wrap_aware(words, seg=4096, stride=STRIDE):
+    """candidate: quantile classes by kappa as now, but inside a class the entries go to the groups by their theta_u
+    rank, rotated from class to class so that theta_u falls by one bank step per lane of a group: the entries a hit
+    angle wraps (bin 0 -> 29) are then the first lanes of every group and meet no unwrapped entry two banks on"""
+    out = words.copy()
+    for s0 in range(0, len(words), seg):
+        w = words[s0:s0 + seg]
+        n = len(w)
+        if n < 64:
+            continue
+        G = (n + 31) // 32
+        srt = w[np.argsort(key_kappa(w, stride), kind="stable")]
+        u = (srt >> 11)
+        newsrt = srt.copy()
+        for h in range(32):
+            lo, hi = h * n // 32, (h + 1) * n // 32          # quantile class h
+            cls = srt[lo:hi]
+            m = len(cls)
+            if m == 0:
+                continue
+            byu = cls[np.argsort(u[lo:hi], kind="stable")]
+            rot = (h * m) // 32
+            # position r in the class goes to group (r) ; it should hold u-rank (r - rot) mod m
+            idx = (np.arange(m) - rot) % m
+            newsrt[lo:hi] = byu[idx]
+        # deal: same positions as spread_order
+        p = np.arange(n)
+        c, q = p >> 8, p & 255
+        lane, j = q >> 2, q & 3
+        h_, g = lane & 31, lane >> 5
+        order = np.lexsort((g, j, c, h_))
+        out[s0 + order] = newsrt
+    return out
+
+
+if __name__ == "__main__" and len(sys.argv) > 3:
+    d = np.load(sys.argv[1])
+    words, offs, runs = d["words"], d["offs"], d["runs"]
+    ns = int(sys.argv[2])
+    rng = np.random.default_rng(0)
+    lens = (offs[1:] - offs[:-1])[runs[:, 0]]
+    wgt = runs[:, 1] * lens
+    pick = rng.choice(len(runs), ns, p=wgt / wgt.sum())
+    for name, fn in (("wrap-aware", spread_wrap_aware),):
+        tot = []
+        for r in pick:
+            b = runs[r, 0]
+            w = fn(words[offs[b]:offs[b + 1]])
+            for s in rng.uniform(0, 30, 2):
+                tot.append(cycles(w, s))
+        c = np.concatenate(tot)
+        print("%-14s array cycles/instr %.3f   max(4,.) %.3f   share >4: %.3f" % (name, c.mean(), np.maximum(c, 4).mean(), (c > 4).mean()))
+
+
+def spread_lattice(words, seg=4096, stride=STRIDE, bsel=None):
+    """candidate: quantile classes by kappa (32 per segment, G entries each); a class is cut into `a` runs of b
+    consecutive kappa ranks, each run ordered by theta_u and rotated from class to class; group (i, r) takes rank r of
+    run i: kappa as precise as a run is narrow (1/a of a bank), theta_u falling along the group in steps of 30/b"""
+    out = words.copy()
+    for s0 in range(0, len(words), seg):
+        w = words[s0:s0 + seg]
+        n = len(w)
+        if n < 64:
+            continue
+        srt = w[np.argsort(key_kappa(w, stride), kind="stable")]
+        u = (srt >> 11)
+        newsrt = srt.copy()
+        for h in range(32):
+            lo, hi = h * n // 32, (h + 1) * n // 32
+            m = hi - lo
+            if m < 2:
+                continue
+            b = bsel(m) if bsel else max(1, int(round(np.sqrt(m))))
+            for r0 in range(0, m, b):
+                r1 = min(m, r0 + b)
+                mb = r1 - r0
+                blk = srt[lo + r0:lo + r1]
+                byu = blk[np.argsort(u[lo + r0:lo + r1], kind="stable")[::-1]]     # theta_u descending
+                rot = (h * mb) // 32
+                newsrt[lo + r0:lo + r1] = byu[(np.arange(mb) + rot) % mb]
+        p = np.arange(n)
+        c, q = p >> 8, p & 255
+        lane, j = q >> 2, q & 3
+        h_, g = lane & 31, lane >> 5
+        order = np.lexsort((g, j, c, h_))
+        out[s0 + order] = newsrt
+    return out
