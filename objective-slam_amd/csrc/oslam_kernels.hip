@@ -8,25 +8,27 @@
  *   model build : pair key -> per-slice open-addressing table -> bucketed
  *                 4-byte pair entries (two counting passes, no sort); union table
  *                 of all keys, and per slice the bucket of every union slot; bitset
- *                 of the distance bins that can reach a key; entries ordered inside
- *                 each bucket for the LDS banks;
+ *                 of the distance bins that can reach a key; key map (distance bin,
+ *                 three angle bins) -> union slot; entries ordered inside each
+ *                 bucket for the LDS banks;
  *   scene count : per reference point, the pairs whose distance bin can reach a
  *                 model key: sizes the hit lists by demand;
- *   scene keys  : per (reference r, tile of scene points): distance bin of every
- *                 pair, unreachable bins dropped, the rest compacted in LDS; full
- *                 key -> union-table probe -> per-reference hit list
- *                 {union slot} + {theta_v, i} written by wave-aggregated appends;
+ *   scene keys  : per (8 reference points, tile of scene points): distance bin of
+ *                 every pair, unreachable bins dropped, the rest compacted in LDS;
+ *                 the pair's feature as bins -> key map (one load, no hash, no
+ *                 probing) -> per-reference hit list {union slot} + {theta_v, i}
+ *                 written by wave-aggregated appends;
  *   hit sort    : per reference point, hits ordered by union slot (LDS radix
  *                 sort) and the list of runs of equal keys;
- *   voting      : one workgroup per (scene reference point, model slice): a run
- *                 finds its bucket with one load (no probing); very long items are
- *                 cut into units dealt to the 16 waves, the rest is handed out
- *                 dynamically a few runs at a time; a wave streams a bucket once
- *                 for all hits that share it (16 bytes = 4 entries per lane, next
- *                 step's loads in flight) -> integer alpha bin -> LDS accumulator
- *                 [1024 model refs][32 alpha bins]; votes near a bin edge queued
- *                 and re-evaluated with the reference's float sequence; in-kernel
- *                 peak extraction;
+ *   voting      : one workgroup per (scene reference point, model slice of 2046
+ *                 points): a run finds its bucket with one load (no probing); very
+ *                 long items are cut into units dealt to the 16 waves, the rest is
+ *                 handed out dynamically a few runs at a time; a wave streams a
+ *                 bucket once for all hits that share it (16 bytes = 4 entries per
+ *                 lane, four steps' loads in flight) -> integer alpha bin -> LDS
+ *                 accumulator [1023 rows + sink][31 words], two 16-bit counters per
+ *                 word; votes near a bin edge are cast, noted and re-checked with
+ *                 the reference's float sequence; in-kernel peak extraction;
  *   clustering  : scores of the candidate poses (one wave per pose).
  */
 #include <hip/hip_runtime.h>
@@ -424,14 +426,13 @@ __device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
 /* ---- the vote of one (model pair entry, scene hit) ---------------------------
  * A wave holds a chunk of 256 model-pair entries in registers: lane l has entries 4l .. 4l+3
  * of the chunk (one 16-byte load).  Every hit of the run votes with the chunk:
- *     tm  = hit's base (4*(theta_v + half a turn) + margin, one SGPR) - 4*theta_u
- *     bin = v_mul_hi_u32_u24(tm, 7680);  position = v_mul_u32_u24(tm, 7680)
+ *     tm  = hit's base (theta_v + half a turn + margin, scaled; one SGPR) - the entry word as stored
+ *     {bin, position} = v_mad_u64_u32(tm, 30)
  * Only positions within the margin of a bin edge (0.05 % of votes) are re-evaluated with the
  * reference's float sequence via pc_alpha_bin_table (ppf_core.h), so the bins are the
- * reference's.  The code is straight-line: lanes past the end of the bucket add into trash
- * words behind the accumulator instead of branching around the atomic. */
-#define ACC_TRASH ACC_CELLS            /* 64 + 32 words: lane's word + bin */
-#define ACC_TRASH_WORDS 96
+ * reference's.  The code is straight-line: lanes past the end of the bucket are masked out of
+ * the atomics (EXEC), padding entries vote into the accumulator's sink row. */
+#define ACC_TRASH_WORDS 96              /* slack behind the accumulator (16-byte zeroing, alignment of what follows) */
 
 /* what the re-evaluation of a vote reads besides the entry: the reference point's hit list, the
  * scene cloud and the rows y,z of T_s_g (kernel.cu:334-336) */
@@ -564,11 +565,11 @@ __device__ __forceinline__ uint32_t forced_item(lds_ctx *sc, lds_u32 *acc, lds_u
 /* The registers of a step in flight and its votes: lane l holds entries 4l .. 4l+3 of the chunk (one
  * 16-byte load) and theta_v of hit `lane` of the run.  One code path for full and partial chunks: the
  * atomics are issued with EXEC narrowed to the lanes that hold entries, so idle lanes cost no LDS cycles
- * and cause no bank conflicts; the one lane that holds fewer than four entries sends the rest to its
- * trash word.  Written in asm because the compiler has no way to say this; the workgroup waits for these
- * atomics (lgkmcnt) before it reads the accumulator.  Per hit (256 votes): readlane + 19 vector
- * instructions (exact mode) + compare/branch + 4 LDS atomics + loop control.  Items that carry a marker
- * never come here (forced_item). */
+ * and cause no bank conflicts; the padding behind a bucket votes into the sink row.  Written in asm because
+ * the compiler has no way to say this; the workgroup waits for these atomics (lgkmcnt) before it reads the
+ * accumulator.  Per hit (256 votes): v_readlane + 4 x (v_sub, v_mad_u64_u32, v_lshl_add) + (exact mode)
+ * v_min, v_min3, v_cmp = 16 vector instructions, 60 cycles of a SIMD + 4 LDS atomics + loop control.  Items
+ * that carry a marker never come here (forced_item). */
 template <int MODE>
 struct VoteRegs {
     uint4 v;
