@@ -885,11 +885,8 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
 #define SORT_THREADS 1024
 #define SORT_ITEMS (SORT_MAX / SORT_THREADS)
 #define SORT_SMALL_ITEMS 2                      /* lists of up to 2048 hits (small scenes) take a 2-per-thread sort */
-#ifndef SORT_RADIX_BITS
-#define SORT_RADIX_BITS 0                       /* 0 = rocPRIM's choice (8 bits per pass, warp-match ranking) */
-#endif
-typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_ITEMS, uint32_t, 1, 1, SORT_RADIX_BITS> hit_block_sort;
-typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_SMALL_ITEMS, uint32_t, 1, 1, SORT_RADIX_BITS> hit_block_sort_small;
+typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_ITEMS, uint32_t> hit_block_sort;
+typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_SMALL_ITEMS, uint32_t> hit_block_sort_small;
 
 /* One segment of n <= ITEMS * 1024 hits: sort, gather, run heads.  Returns the segment's run count (the
  * same value in every thread). */
