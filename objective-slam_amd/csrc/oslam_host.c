@@ -349,6 +349,7 @@ void oslam_model_destroy(oslam_model *m)
     if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
     if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
     if (m->table.kmap && !m->shared_union) (void)hipFree(m->table.kmap);
+    if (m->table.uids && !m->shared_union) (void)hipFree(m->table.uids);
     if (m->d_counters) (void)hipFree(m->d_counters);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_union) (void)hipFree(m->d_union);
@@ -365,17 +366,31 @@ void oslam_model_destroy(oslam_model *m)
     free(m);
 }
 
-/* table.kmap and table.reach_words from table.ukeys / table.reach (both complete on g_stream): the slot of every
- * key a reachable distance bin can produce, so that the scene-key kernel looks a pair up with one load.  17^3
- * words per reachable distance bin (0.8 MB for a model that spans 41 bins). */
+/* table.uids, table.kmap and table.reach_words from table.ukeys / table.reach (both complete on g_stream): the keys
+ * numbered, and the number of every key a reachable distance bin can produce, so that the scene-key kernel looks a
+ * pair up with one load.  17^3 words per reachable distance bin (0.8 MB for a model that spans 41 bins). */
 static int build_kmap(oslamk_table *t, float d_dist)
 {
     int rc = OSLAM_OK;
-    uint32_t h_reach[OSLAMK_REACH_BINS / 32], w, top = 0;
+    uint32_t h_reach[OSLAMK_REACH_BINS / 32], w, top = 0, n_ids = 0, *d_count = NULL;
     t->kmap = NULL;
     t->kmap_bins = 0;
     t->reach_words = 0;
+    t->uids = NULL;
+    t->n_ids = t->id_bits = t->uinfo_stride = 0;
+    /* the keys of the union table numbered 0 .. n_ids-1: what the hit lists carry and sort on, and what the bucket
+     * records are indexed by */
+    HIPCHK(hipMalloc((void **)&t->uids, sizeof(uint32_t) * (size_t)t->ucap));
+    HIPCHK(hipMalloc((void **)&d_count, sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), (hipStream_t)g_stream));
+    KCHK(oslamk_union_ids(*t, d_count, g_stream));
+    HIPCHK(hipMemcpyAsync(&n_ids, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)g_stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+    t->n_ids = n_ids;
+    t->id_bits = 1;
+    while (t->id_bits < 32u && ((uint64_t)1 << t->id_bits) < (uint64_t)n_ids) t->id_bits++;
+    t->uinfo_stride = (n_ids + 63u) & ~63u;
+    if (t->uinfo_stride == 0) t->uinfo_stride = 64;
     HIPCHK(hipMemcpy(h_reach, t->reach, sizeof h_reach, hipMemcpyDeviceToHost));
     for (w = 0; w < OSLAMK_REACH_BINS / 32; w++)
         if (h_reach[w]) {
@@ -383,10 +398,12 @@ static int build_kmap(oslamk_table *t, float d_dist)
             top = 32u * w + (32u - (uint32_t)__builtin_clz(h_reach[w]));    /* highest reachable bin + 1 */
         }
     t->kmap_bins = top < OSLAMK_KMAP_MAX_BINS ? top : OSLAMK_KMAP_MAX_BINS;
-    if (t->kmap_bins == 0) return OSLAM_OK;
-    HIPCHK(hipMalloc((void **)&t->kmap, sizeof(uint32_t) * (size_t)t->kmap_bins * PC_ANGLE_COMBOS));
-    KCHK(oslamk_kmap_build(*t, d_dist, g_stream));
+    if (t->kmap_bins) {
+        HIPCHK(hipMalloc((void **)&t->kmap, sizeof(uint32_t) * (size_t)t->kmap_bins * PC_ANGLE_COMBOS));
+        KCHK(oslamk_kmap_build(*t, d_dist, g_stream));
+    }
 done:
+    if (d_count) (void)hipFree(d_count);
     return rc;
 }
 
@@ -401,9 +418,11 @@ static int build_union(oslam_model *m, uint32_t distinct, uint32_t *d_n_keys, ui
     if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
     if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
     if (m->table.kmap && !m->shared_union) (void)hipFree(m->table.kmap);
+    if (m->table.uids && !m->shared_union) (void)hipFree(m->table.uids);
     m->table.ukeys = NULL;
     m->table.reach = NULL;
     m->table.kmap = NULL;
+    m->table.uids = NULL;
     m->shared_union = 0;
     m->table.ucap = 1u << lg;
     m->table.ushift = 32 - lg;
@@ -425,7 +444,7 @@ done:
 static int build_uinfo(oslam_model *m)
 {
     int rc = OSLAM_OK;
-    const size_t bytes = sizeof(oslamk_uinfo) * (size_t)m->table.n_slices * (size_t)m->table.ucap;
+    const size_t bytes = sizeof(oslamk_uinfo) * (size_t)m->table.n_slices * (size_t)m->table.uinfo_stride;
     if (m->table.uinfo) { (void)hipFree(m->table.uinfo); m->table.uinfo = NULL; }
     HIPCHK(hipMalloc((void **)&m->table.uinfo, bytes));
     HIPCHK(hipMemsetAsync(m->table.uinfo, 0, bytes, (hipStream_t)g_stream));
@@ -778,7 +797,7 @@ int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint
     if (table_bytes)
         *table_bytes = sizeof(oslamk_slot) * (uint64_t)m->table.cap * (uint64_t)m->table.n_slices +
                        sizeof(uint32_t) * (uint64_t)m->table.ucap + sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32) +
-                       sizeof(oslamk_uinfo) * (uint64_t)m->table.ucap * (uint64_t)m->table.n_slices +
+                       sizeof(oslamk_uinfo) * (uint64_t)m->table.uinfo_stride * (uint64_t)m->table.n_slices +
                        (uint64_t)m->n_entries * (4 + 2 + (m->ent.uv ? 8 : 0)) + 24ull * (uint64_t)m->c.n;
     return OSLAM_OK;
 }
@@ -1864,7 +1883,7 @@ done:
 typedef struct db_group {
     int n;
     size_t *members;                  /* indices into db->models */
-    uint32_t *ukeys, *reach, *kmap;   /* the group's union table, reachable-distance bitset and key map (n > 1) */
+    uint32_t *ukeys, *reach, *kmap, *uids;   /* the group's union table, reachable-distance bitset, key map and key numbers (n > 1) */
 } db_group;
 
 struct oslam_db {
@@ -1900,6 +1919,7 @@ void oslam_db_destroy(oslam_db *db)
             if (gr->ukeys) (void)hipFree(gr->ukeys);
             if (gr->reach) (void)hipFree(gr->reach);
             if (gr->kmap) (void)hipFree(gr->kmap);
+            if (gr->uids) (void)hipFree(gr->uids);
         }
         free(gr->members);
     }
@@ -1969,6 +1989,7 @@ int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
         KCHK(oslamk_reach_build(t, models[gr->members[0]]->d_dist, g_stream));
         rc = build_kmap(&t, models[gr->members[0]]->d_dist);
         gr->kmap = t.kmap;
+        gr->uids = t.uids;
         if (rc != OSLAM_OK) goto done;
         HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
         HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
@@ -1979,11 +2000,16 @@ int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
             (void)hipFree(m->table.ukeys);
             (void)hipFree(m->table.reach);
             if (m->table.kmap) (void)hipFree(m->table.kmap);
+            if (m->table.uids) (void)hipFree(m->table.uids);
             m->table.ukeys = gr->ukeys;
             m->table.reach = gr->reach;
             m->table.kmap = gr->kmap;
+            m->table.uids = gr->uids;
             m->table.kmap_bins = t.kmap_bins;
             m->table.reach_words = t.reach_words;
+            m->table.n_ids = t.n_ids;
+            m->table.id_bits = t.id_bits;
+            m->table.uinfo_stride = t.uinfo_stride;
             m->table.ucap = 1u << lg;
             m->table.ushift = 32 - lg;
             m->shared_union = 1;

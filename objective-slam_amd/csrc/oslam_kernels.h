@@ -70,12 +70,18 @@ typedef struct oslamk_table {
      * (FNV collisions included), k1 < OSLAMK_REACH_BINS; pairs in other bins cannot hit */
     uint32_t *reach;
     uint32_t reach_words;      /* words of `reach` up to and including the last one that has a bit set */
-    /* kmap[k1 * 17^3 + combo], k1 < kmap_bins: the union-table slot of the key that distance bin k1 and the
+    /* kmap[k1 * 17^3 + combo], k1 < kmap_bins: the number (uids) of the key that distance bin k1 and the
      * angle bins `combo` hash to (pc_key_of_bins), or OSLAMK_KMAP_NONE; covers every reachable bin unless the
      * model spans more than OSLAMK_KMAP_MAX_BINS of them (the rest are hashed and probed) */
-    uint32_t *kmap;
+    uint32_t *kmap;            /* holds key numbers (uids), not slots */
     uint32_t kmap_bins;
-    oslamk_uinfo *uinfo;       /* [n_slices][ucap] */
+    /* uids[slot]: the dense number (0 .. n_ids-1) of the key in union-table slot `slot`.  From the scene-key
+     * kernel on a key is known by this number: the hit lists sort on id_bits = ceil(log2 n_ids) bits (16 for the
+     * 38 000 keys of a 5 k-point model: two 8-bit passes instead of three) and the bucket records below take
+     * 8 B x n_ids per slice instead of 8 B x ucap */
+    uint32_t *uids;
+    uint32_t n_ids, id_bits, uinfo_stride;
+    oslamk_uinfo *uinfo;       /* [n_slices][uinfo_stride], indexed by the key's number */
 } oslamk_table;
 #define OSLAMK_KMAP_NONE 0xffffffffu
 #define OSLAMK_KMAP_MAX_BINS 2048
@@ -116,7 +122,9 @@ int oslamk_table_scan(oslamk_table t, uint32_t *total_out, void *stream);
 int oslamk_union_build(oslamk_table t, uint32_t *n_keys, uint32_t *overflow, void *stream);
 /* fill t.reach by enumerating every key each distance bin can produce */
 int oslamk_reach_build(oslamk_table t, float d_dist, void *stream);
-/* fill t.kmap (t.kmap_bins rows) from t.ukeys */
+/* t.uids[slot] = 0, 1, 2, ... for the slots of t.ukeys that hold a key; *counter (zero on entry) ends as their number */
+int oslamk_union_ids(oslamk_table t, uint32_t *counter, void *stream);
+/* fill t.kmap (t.kmap_bins rows) from t.ukeys / t.uids */
 int oslamk_kmap_build(oslamk_table t, float d_dist, void *stream);
 /* model build, pass 2: write entries. tmg = [M][8] rows y,z of T_m_g (host-computed). */
 int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_table t,

@@ -197,7 +197,14 @@ __global__ __launch_bounds__(256) void k_reach_build(oslamk_table t, float d_dis
     if (threadIdx.x == 0 && s_found) atomicOr(&t.reach[k1 >> 5], 1u << (k1 & 31u));
 }
 
-/* table.kmap[k1][combo] = the slot in the union table of the key that distance bin k1 and the angle bins
+/* table.uids: the keys of the union table numbered 0 .. n-1 (any order).  One thread per slot. */
+__global__ void k_union_ids(oslamk_table t, uint32_t *counter)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < t.ucap && t.ukeys[slot] != 0u) t.uids[slot] = atomicAdd(counter, 1u);
+}
+
+/* table.kmap[k1][combo] = the number (table.uids) of the key that distance bin k1 and the angle bins
  * `combo` hash to (pc_key_of_bins), or OSLAMK_KMAP_NONE: the scene-key kernel then needs neither the hash nor
  * a probe sequence.  One workgroup per distance bin k1 < table.kmap_bins. */
 __global__ __launch_bounds__(256) void k_kmap_build(oslamk_table t, float d_dist)
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void k_kmap_build(oslamk_table t, float d_dist
             uint32_t slot = slot_of(key, t.ushift);
             for (uint32_t probe = 0; probe <= mask; probe++) {
                 const uint32_t k = t.ukeys[slot];
-                if (k == key) { found = slot; break; }
+                if (k == key) { found = t.uids[slot]; break; }
                 if (k == 0) break;
                 slot = (slot + 1) & mask;
             }
@@ -236,7 +243,7 @@ __global__ void k_uinfo_build(oslamk_table t)
             oslamk_uinfo ui;
             ui.start = sl.start;
             ui.len = sl.len | (sl.cur & 0x80000000u);      /* bit 31 of the fill cursor: marker entry in the bucket */
-            t.uinfo[(idx / t.cap) * (size_t)t.ucap + slot] = ui;
+            t.uinfo[(idx / t.cap) * (size_t)t.uinfo_stride + t.uids[slot]] = ui;
             return;
         }
         slot = (slot + 1) & mask;
@@ -789,6 +796,7 @@ __device__ __forceinline__ void hits_chunk(const oslamk_vote_args &a, int ref_lo
                     if (k == 0) break;
                     slot = (slot + 1) & mask;
                 }
+                if (hit) slot = a.table.uids[slot];                /* the key's number, as the key map gives it */
             }
         }
         if (hit) {
@@ -984,7 +992,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const uint32_t n_all = a.hit_count[ref_local];
     const size_t off = a.hit_off[ref_local];
-    const unsigned bits = 32u - a.table.ushift;
+    const unsigned bits = a.table.id_bits;
     uint32_t n_runs = 0;                /* the same value in every thread */
     for (uint32_t seg = 0; seg < n_all; seg += SORT_MAX) {
         const uint32_t n = n_all - seg < SORT_MAX ? n_all - seg : SORT_MAX;
@@ -1067,7 +1075,7 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
     const size_t off = a.hit_off[ref_local];
     const oslamk_pay *hits = a.hit_sorted + off;
     const oslamk_run *runs = a.runs + off;
-    const oslamk_uinfo *uinfo = a.table.uinfo + (size_t)slice * a.table.ucap;
+    const oslamk_uinfo *uinfo = a.table.uinfo + (size_t)slice * a.table.uinfo_stride;
     const uint32_t *e4 = a.ent.e4;
     const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
     if (tid == 0) {
@@ -1645,6 +1653,12 @@ int oslamk_bucket_spread(oslamk_table t, oslamk_entries ent, void *stream)
 int oslamk_reach_build(oslamk_table t, float d_dist, void *stream)
 {
     hipLaunchKernelGGL(k_reach_build, dim3(OSLAMK_REACH_BINS), dim3(256), 0, (hipStream_t)stream, t, d_dist);
+    return (int)hipGetLastError();
+}
+
+int oslamk_union_ids(oslamk_table t, uint32_t *counter, void *stream)
+{
+    hipLaunchKernelGGL(k_union_ids, dim3((t.ucap + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, t, counter);
     return (int)hipGetLastError();
 }
 
