@@ -31,6 +31,7 @@ extern "C" {
 #define OSLAM_E_NOMEM 3
 #define OSLAM_E_NO_VOTES 4    /* no scene pair matched the model: T is all zeros */
 #define OSLAM_E_LIMIT 5       /* cloud exceeds an encoding limit (see oslam_model_create) */
+#define OSLAM_E_PEER 6        /* multi-GPU: another rank failed; every rank abandoned the registration together */
 
 /* Per-vote arithmetic of the alpha angle (reference src/cuda/kernel.cu:302-342). */
 #define OSLAM_VOTE_EXACT 0    /* accumulator identical to the reference's: alpha from quantised angles,
@@ -54,7 +55,13 @@ typedef struct oslam_params {
     int shard_world;               /* default 1 */
     unsigned max_cells;            /* initial capacity of the peak-record buffer, default 1<<22; it grows (to at most
                                     * 2^28 records) when more cells than that lie above the threshold */
-    int reserved[6];
+    unsigned pose_gpu_min;         /* peak records from which the pose tail runs on the device; 0 = default (4096).  Both
+                                    * tails give identical results; tests force either one */
+    int no_bucket_spread;          /* model build: skip the pass that orders every bucket for the LDS banks (A/B
+                                    * measurements; the accumulators do not depend on the order) */
+    unsigned scratch_gib;          /* limit of the device's hit-list pool in GiB; 0 = default (4).  A registration
+                                    * whose lists need more runs in batches of reference points */
+    int reserved[3];
 } oslam_params;
 
 /* Counters the reference logs at debug level (model.cu:122,152,161-168;
@@ -154,6 +161,9 @@ int oslam_align_prepare(oslam_model *m, oslam_scene *s);
 typedef struct oslam_db oslam_db;
 int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out);
 void oslam_db_destroy(oslam_db *db);
+/* the same, for a caller that destroys the models right afterwards: the members do not get their own key
+ * tables back (they cannot be aligned any more, only destroyed) */
+void oslam_db_destroy_with_models(oslam_db *db);
 int oslam_db_align(oslam_db *db, oslam_scene *s, float *T_out, oslam_stats *stats);
 int oslam_db_size(const oslam_db *db, size_t *n_models, size_t *n_groups);
 
@@ -261,6 +271,36 @@ int oslam_comm_unique_id(void *id_out);
 int oslam_comm_create(const void *id, int rank, int world, int dev, oslam_comm **out);
 void oslam_comm_destroy(oslam_comm *c);
 int oslam_align_multi(oslam_model *m, oslam_scene *s, oslam_comm *c, float T_rowmajor[16], oslam_stats *stats);
+/* Failure is collective: when one rank cannot go on between two collectives (no memory, too many
+ * peaks, a failed kernel) an error word travels with the next collective and EVERY rank returns --
+ * the failing one with its own code, the others with OSLAM_E_PEER; nobody is left waiting.  A
+ * collective that fails itself aborts the communicator (ncclCommAbort): the handle then refuses
+ * further calls (OSLAM_E_DEVICE) and a new one has to be made.
+ *
+ * Loopback communicator: `world` emulated ranks that share ONE device inside one process (one
+ * thread per rank calls oslam_align_multi with its own model, scene shard and handle out[r]).  The
+ * collectives become device-to-device copies between pthread barriers (which time out instead of
+ * hanging).  It runs the same exchange code as RCCL does -- that is its purpose: the N > 1 state
+ * machine can be executed, and its failure paths injected, on a box with one GPU. */
+int oslam_comm_create_loopback(int world, int dev, oslam_comm **out /* [world] */);
+int oslam_comm_info(const oslam_comm *c, int *rank, int *world, int *broken);
+/* gives the communicator up without waiting for anybody (ncclCommAbort): for a rank that cannot take part in an
+ * exchange its peers have entered or will enter.  The handle refuses every later call; peers that use the
+ * loopback transport are released with an error, RCCL peers stay in their collective until they abort too. */
+int oslam_comm_abort(oslam_comm *c);
+/* test tap: the next exchange on this handle fails locally at `stage` (1 = after the votes, 2 = while
+ * selecting the survivors, 3 = while growing the record buffer), as an allocation failure would */
+int oslam_comm_inject_failure(oslam_comm *c, int stage);
+
+/* A database split by MODEL instead of by reference point (SURVEY 8e's alternative; what the scenes x models
+ * loop of src/cuda/ppf.cu:57-100 becomes on several GPUs when the database is large): model j of n_total lives
+ * on rank j % world, `db` holds this rank's models in that order (j = rank, rank + world, ...; may be NULL on a
+ * rank without models), `s` is the WHOLE scene (no reference-point shard).  Every rank registers its models
+ * (oslam_db_align), then one all-gather of 17 floats per model through the communicator gives every rank all
+ * poses: T_out[j*16..] for j < n_total, found_out[j] (may be NULL) = 1 when model j produced a pose, 0 when
+ * nothing matched.  No exchange on the vote path. */
+int oslam_db_align_multi(oslam_db *db, oslam_scene *s, oslam_comm *c, size_t n_total, float *T_out, int *found_out,
+                         oslam_stats *stats_local);
 
 /* Host-buffer form of the same exchange, for callers with their own transport (and the CPU tests
  * over gloo).  oslam_align_local runs this rank's votes and reports the number of peak records

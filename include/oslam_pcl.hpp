@@ -169,33 +169,35 @@ std::vector<std::vector<Matrix4>> ppf_registration(std::vector<CloudPtr> scene_c
     for (std::size_t j = 0; j < model_clouds.size(); j++)
         models.emplace_back(new Model<CloudT>(&*model_clouds[j], model_d_dists[j], vote_count_threshold,
                                               cpu_clustering, use_l1_norm, use_averaged_clusters, devUse));
+    /* The scenes x models loop of ppf.cu:57-100 as a resident database (oslam_db): models that share a d_dist
+     * share the scene pass of every frame, and ONE scene object (d_dist 0: its pair keys are made per group of
+     * models inside the align, where the reference prepares the scene per model, ppf.cu:64-67) serves them all.
+     * oslam_db_align returns what ppf.cu:74-93 extracts (the pose of max_idx with the clustered translation, or
+     * the winning cluster's pose with cpu_clustering); the per-model result fields stay available through
+     * Model::ppf_lookup for callers that want them. */
+    struct DbGuard {
+        oslam_db *h = nullptr;
+        ~DbGuard() { oslam_db_destroy_with_models(h); }      /* the models are destroyed right after */
+    } db;
+    if (!models.empty()) {
+        std::vector<oslam_model *> handles;
+        for (auto &m : models) handles.push_back(m->handle());
+        check(oslam_db_create(handles.data(), handles.size(), &db.h));
+    }
     oslam_params sp;
     oslam_params_default(&sp);
     sp.dev = devUse;
+    std::vector<float> T(16 * (models.empty() ? 1 : models.size()));
     for (std::size_t i = 0; i < scene_clouds.size(); i++) {
         results.push_back(std::vector<Matrix4>());
-        for (std::size_t j = 0; j < model_clouds.size(); j++) {
-            /* the scene is prepared per model: its keys depend on the model's d_dist (ppf.cu:64-67) */
-            Scene<CloudT> scene(&*scene_clouds[i], model_d_dists[j], ref_point_downsample_factor, &sp);
-            Model<CloudT> *model = models[j].get();
-            model->ppf_lookup(&scene);
-            Matrix4 T;
-            /* the extraction of ppf.cu:74-93, from the same fields */
-            if (cpu_clustering && !model->cpu_transformations.empty()) {
-                for (int r = 0; r < 4; r++)
-                    for (int c = 0; c < 4; c++) T(r, c) = model->cpu_transformations[0].pose[4 * r + c];
-            } else if (model->transformation_trans.size() >= 2) {
-                const std::vector<float> &transformations = model->getTransformations();
-                for (int r = 0; r < 4; r++)
-                    for (int c = 0; c < 4; c++) T(r, c) = transformations[model->max_idx * 16 + r * 4 + c];
-                T(0, 3) = model->transformation_trans[model->max_idx].x;
-                T(1, 3) = model->transformation_trans[model->max_idx].y;
-                T(2, 3) = model->transformation_trans[model->max_idx].z;
-            } else {                                 /* no cell, or a single one: the zero pose (kernel.cu:609) */
-                for (int r = 0; r < 4; r++)
-                    for (int c = 0; c < 4; c++) T(r, c) = model->best_T[4 * r + c];
-            }
-            results.back().push_back(T);
+        if (models.empty()) continue;
+        Scene<CloudT> scene(&*scene_clouds[i], 0.0f, ref_point_downsample_factor, &sp);
+        check(oslam_db_align(db.h, scene.handle(), T.data(), nullptr));
+        for (std::size_t j = 0; j < models.size(); j++) {
+            Matrix4 M;
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) M(r, c) = T[16 * j + 4 * r + c];
+            results.back().push_back(M);
         }
     }
     return results;

@@ -16,9 +16,8 @@
 #include <string.h>
 #include <time.h>
 
-#include <rccl/rccl.h>
-
 #include "oslam.h"
+#include "oslam_comm.h"
 #include "oslam_kernels.h"
 #include "oslam_pose.h"
 #include "ppf_core.h"
@@ -36,9 +35,11 @@ int oslam_set_stream(void *hip_stream)
 
 static int fail(int code, const char *what)
 {
-    snprintf(g_err, sizeof g_err, "%s", what);
+    if (what != g_err) snprintf(g_err, sizeof g_err, "%s", what);
     return code;
 }
+
+int oslam_fail(int code, const char *what) { return fail(code, what); }
 
 #define HIPCHK(call)                                                                      \
     do {                                                                                  \
@@ -84,6 +85,9 @@ int oslam_params_default(oslam_params *p)
     p->shard_rank = 0;
     p->shard_world = 1;
     p->max_cells = 1u << 22;
+    p->pose_gpu_min = 0;              /* 0 = default (4096 records) */
+    p->no_bucket_spread = 0;
+    p->scratch_gib = 0;               /* 0 = default (4 GiB) */
     return OSLAM_OK;
 }
 
@@ -151,6 +155,9 @@ struct oslam_model {
     oslamk_slot *h_slots;
     /* member of a database group: table.ukeys / reach belong to the group (oslam_db) */
     int shared_union;
+    /* its key tables are gone (a database was destroyed without giving them back, or rebuilding them failed):
+     * the model can only be destroyed */
+    int unusable;
 };
 
 struct oslam_scene {
@@ -536,7 +543,7 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     /* every word a padding entry until the fill pass writes it: padding votes into the accumulator's sink row */
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->ent.e4, (int)PC_ROW_SINK, n_pairs + 256, (hipStream_t)g_stream));
     KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->ent, g_stream));
-    if (!getenv("OSLAM_NO_SPREAD")) KCHK(oslamk_bucket_spread(m->table, m->ent, g_stream));   /* the switch is for A/B measurements */
+    if (!m->params.no_bucket_spread) KCHK(oslamk_bucket_spread(m->table, m->ent, g_stream));   /* the switch is for A/B measurements */
     rc = build_uinfo(m);
     if (rc != OSLAM_OK) goto done;
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
@@ -948,6 +955,7 @@ done:
 static int check_pair(const oslam_model *m, const oslam_scene *s)
 {
     if (!m || !s) return fail(OSLAM_E_INVALID, "NULL handle");
+    if (m->unusable) return fail(OSLAM_E_INVALID, "this model lost its key tables with its database: it can only be destroyed");
     if (m->dev != s->dev) return fail(OSLAM_E_INVALID, "model and scene live on different devices");
     /* d_dist 0 = a scene for models of any d_dist: nothing a scene holds here depends on it */
     if (s->d_dist != 0.0f && m->d_dist != s->d_dist) return fail(OSLAM_E_INVALID, "scene d_dist differs from the model's (ppf.cu:64-67)");
@@ -1031,10 +1039,9 @@ int oslam_release_scratch(int dev)
     return OSLAM_OK;
 }
 
-static size_t scratch_limit(void)
+static size_t scratch_limit(const oslam_model *m)
 {
-    const char *env = getenv("OSLAM_SCRATCH_GIB");
-    return (size_t)(env && atoi(env) > 0 ? atoi(env) : 4) << 30;
+    return (size_t)(m && m->params.scratch_gib > 0 ? m->params.scratch_gib : 4) << 30;
 }
 
 /* per-reference counters for n_ref reference points, events */
@@ -1061,13 +1068,16 @@ done:
     return rc;
 }
 
-static int pool_reserve_slots(scratch_pool *p, size_t slots)
+static int pool_reserve_slots(scratch_pool *p, size_t slots, size_t limit)
 {
-    size_t want = (slots ? slots : 1) * SLOT_BYTES + 1024;      /* + a wave of hits: the vote kernel loads 64 at a time */
+    const size_t base = (slots ? slots : 1) * SLOT_BYTES + 1024;      /* + a wave of hits: the vote kernel loads 64 at a time */
+    size_t want = base;
     if (p->bytes >= want) return OSLAM_OK;
     if (p->buf) { (void)hipFree(p->buf); p->buf = NULL; p->bytes = 0; }
     want += want / 8;                 /* head room: the next scene is rarely the same size */
-    if (want > scratch_limit() && slots * SLOT_BYTES <= scratch_limit()) want = scratch_limit();
+    /* batches are cut to the limit: no head room beyond it, but never less than the batch itself needs (a pool
+     * below `base` would be freed and mapped again by every registration) */
+    if (want > limit + 1024) want = base > limit + 1024 ? base : limit + 1024;
     if (hipMalloc((void **)&p->buf, want) != hipSuccess) {
         (void)hipGetLastError();
         p->buf = NULL;
@@ -1131,7 +1141,7 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
     oslamk_vote_args a;
     hipStream_t st = (hipStream_t)g_stream;
     hipEvent_t *ev;
-    const size_t limit_slots = scratch_limit() / SLOT_BYTES;
+    const size_t limit_slots = scratch_limit(ms[0]) / SLOT_BYTES;
     size_t cap, max_batch_slots = 0;
     uint32_t *h_keep, *h_off, *d_keep, *d_hitc, *d_runc, *d_off;
     float k0 = 0.0f;
@@ -1204,7 +1214,7 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
             pos += (size_t)n + 1;
             first += n;
         }
-        rc = pool_reserve_slots(pool, max_batch_slots);
+        rc = pool_reserve_slots(pool, max_batch_slots, scratch_limit(ms[0]));
         if (rc != OSLAM_OK) goto done;
         if (pos) HIPCHK(hipMemcpyAsync(d_off, h_off, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, st));
     }
@@ -1250,6 +1260,11 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
     HIPCHK(hipEventRecord(ev[1], st));
     for (j = 0; j < nm; j++) HIPCHK(hipMemcpyAsync(&cnt[j], ms[j]->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (j = 0; j < nm; j++)
+        if (cnt[j].list_overflow) {
+            rc = fail(OSLAM_E_DEVICE, "a hit list overflowed: the counting pass and the hit pass disagreed on the pairs within reach");
+            goto done;
+        }
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, ev[0], ev[1]));
     for (i = 0; i < nb && i < MAX_BATCH_EVENTS; i++) {
         float k = 0.0f, v = 0.0f;
@@ -1342,9 +1357,9 @@ static int vote_and_fetch(scratch_pool *pool, oslam_model *m, oslam_scene *s, os
         }
     }
     if (getenv("OSLAM_PROF"))      /* only a -DVOTE_PROF build fills these */
-        fprintf(stderr, "[oslam prof] k_vote wave cycles: to the end of voting %llu, to the barrier after it %llu, "
+        fprintf(stderr, "[oslam prof] k_vote wave cycles: pre-scan %llu, voting %llu, wait at the barrier behind it %llu, "
                         "peak extraction %llu\n",
-                cnt->prof[0], cnt->prof[1], cnt->prof[2]);
+                cnt->prof[0], cnt->prof[1], cnt->prof[2], cnt->prof[3]);
     *n_cells = cnt->out_count;
     /* the records stay in HBM when the pose tail runs there (leave_on_device_from = its lower bound, 0 = never) */
     if (*n_cells && !(leave_on_device_from && *n_cells >= leave_on_device_from)) {
@@ -1421,17 +1436,12 @@ done:
 }
 
 /* ---- pose tail on the device (oslam_posegpu.hip) for large peak sets ---- */
-static size_t pose_gpu_min(void)
-{
-    const char *e = getenv("OSLAM_POSE_GPU_MIN");        /* tests force the device path at small sizes */
-    return e && atol(e) > 0 ? (size_t)atol(e) : 4096;
-}
 
 /* 0: the tail may run on the device; the host-only variants keep the host path */
 static size_t pose_gpu_from(const oslam_model *m)
 {
     if (m->params.cpu_clustering || m->params.use_averaged_clusters) return 0;
-    return pose_gpu_min();
+    return m->params.pose_gpu_min ? (size_t)m->params.pose_gpu_min : 4096;      /* tests force either tail through the parameter */
 }
 
 static void drop_last(oslam_model *m)
@@ -1448,16 +1458,19 @@ static void drop_last(oslam_model *m)
 static int pose_tables(oslam_model *m, oslam_scene *s)
 {
     int rc = OSLAM_OK;
-    float *h = NULL;
+    float *h = NULL, *d_T = NULL, *d_w = NULL, *d_S = NULL;
     if (!m->d_Tm16) {
         const size_t M = (size_t)m->c.n;
         h = (float *)malloc(sizeof(float) * 16 * M);
         if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
         oslam_T_g_full(m->c.h_xyz, m->c.h_nrm, 0, 1, M, h);
-        HIPCHK(hipMalloc((void **)&m->d_Tm16, sizeof(float) * 16 * M));
-        HIPCHK(hipMemcpy(m->d_Tm16, h, sizeof(float) * 16 * M, hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc((void **)&m->d_weights, sizeof(float) * M));
-        HIPCHK(hipMemcpy(m->d_weights, m->weights, sizeof(float) * M, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&d_T, sizeof(float) * 16 * M));
+        HIPCHK(hipMemcpy(d_T, h, sizeof(float) * 16 * M, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&d_w, sizeof(float) * M));
+        HIPCHK(hipMemcpy(d_w, m->weights, sizeof(float) * M, hipMemcpyHostToDevice));
+        m->d_Tm16 = d_T;                 /* the model owns them only when both are complete */
+        m->d_weights = d_w;
+        d_T = d_w = NULL;
         free(h);
         h = NULL;
     }
@@ -1466,13 +1479,23 @@ static int pose_tables(oslam_model *m, oslam_scene *s)
         h = (float *)malloc(sizeof(float) * 16 * n_all);
         if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
         oslam_T_g_full(s->c.h_xyz, s->c.h_nrm, 0, s->df, n_all, h);
-        HIPCHK(hipMalloc((void **)&s->d_Ts16, sizeof(float) * 16 * n_all));
-        HIPCHK(hipMemcpy(s->d_Ts16, h, sizeof(float) * 16 * n_all, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&d_S, sizeof(float) * 16 * n_all));
+        HIPCHK(hipMemcpy(d_S, h, sizeof(float) * 16 * n_all, hipMemcpyHostToDevice));
+        s->d_Ts16 = d_S;
+        d_S = NULL;
     }
 done:
     free(h);
+    if (d_T) (void)hipFree(d_T);
+    if (d_w) (void)hipFree(d_w);
+    if (d_S) (void)hipFree(d_S);
     return rc;
 }
+
+/* the 64 rotations about x of the pose tail (host libm), made once per process */
+static float g_rotx[128];
+static pthread_once_t g_rotx_once = PTHREAD_ONCE_INIT;
+static void rotx_init(void) { oslam_rotx_table(g_rotx); }
 
 /* Pose tail on the device over the n records in m->d_out.  Returns OSLAM_OK with *done = 1 when it
  * produced the pose; *done = 0 when fewer than two cells survive (the host path handles those). */
@@ -1480,14 +1503,13 @@ static int finish_on_device(oslam_model *m, oslam_scene *s, size_t n, uint32_t g
                             int *done)
 {
     int rc = OSLAM_OK, k;
-    static float rot[128];
-    static int rot_ready;
+    const float *rot = g_rotx;
     uint32_t n_kept = 0, best = 0;
     const float min_votecount = m->params.vote_count_threshold * gmax;      /* model.cu:164 */
     *done = 0;
     rc = pose_tables(m, s);
     if (rc != OSLAM_OK) return rc;
-    if (!rot_ready) { oslam_rotx_table(rot); rot_ready = 1; }
+    pthread_once(&g_rotx_once, rotx_init);
     if (m->pose_cap < n) {
         if (m->d_pose_cells) (void)hipFree(m->d_pose_cells);
         if (m->d_pose_T) (void)hipFree(m->d_pose_T);
@@ -1716,90 +1738,143 @@ done:
     return rc;
 }
 
-/* ---- multi-GPU over RCCL: one call per rank does everything (ppf.h:9-15 is one call too) -------
+/* ---- multi-GPU: one call per rank does everything (ppf.h:9-15 is one call too) -----------------
  * The exchange stays in HBM: all-reduce(MAX) of the vote maxima, the local records filtered with the
- * global threshold where they lie, an all-gather of the survivor counts, one broadcast per rank of its
- * survivors straight into the union buffer (grouped: an all-gather with exact sizes), and the pose
- * tail on the union -- on the device when it is large.  Collectives run on the stream of
- * oslam_set_stream.  Latency-bound: a few KiB to a few hundred KiB per rank over xGMI. */
-struct oslam_comm {
-    ncclComm_t nccl;
-    int rank, world, dev;
-    uint32_t *d_small;                 /* [2 + world]: maximum, count, counts of all ranks */
-    uint32_t *h_small;
-};
-
-static int nccl_fail(ncclResult_t r, const char *what)
+ * global threshold where they lie, an all-gather of the survivor counts, an all-gather with exact
+ * sizes of the survivors straight into the union buffer, and the pose tail on the union -- on the
+ * device when it is large.  The collectives go through the communicator's table of operations
+ * (oslam_comm.h): RCCL over xGMI, or the in-process loopback that lets the same function run with
+ * N emulated ranks on one device.  Latency-bound: a few KiB to a few hundred KiB per rank.
+ *
+ * Failure is collective: whatever goes wrong on ONE rank between two collectives (no memory for the
+ * union, more peaks than the buffers can hold, a failed kernel) travels as an error word beside the
+ * payload of the next collective, so that every rank leaves at the same point -- none is left
+ * waiting in a collective its peer will never enter.  A collective that fails itself aborts the
+ * communicator (ncclCommAbort) and marks it broken. */
+static int peer_failed(void)
 {
-    snprintf(g_err, sizeof g_err, "%s: %s", what, ncclGetErrorString(r));
-    return OSLAM_E_DEVICE;
+    return fail(OSLAM_E_PEER, "a peer rank failed: the registration was abandoned on every rank");
 }
 
-#define NCCLCHK(call)                                  \
-    do {                                               \
-        ncclResult_t r_ = (call);                      \
-        if (r_ != ncclSuccess) {                       \
-            rc = nccl_fail(r_, #call);                 \
-            goto done;                                 \
-        }                                              \
-    } while (0)
-
-int oslam_comm_unique_id(void *id_out)
+/* this rank's n_local records in m->d_out (local maximum lmax, rc_local = what the vote stage returned) ->
+ * the union of every rank's records above the global threshold in m->d_out, *total of them */
+static int exchange_peaks(oslam_model *m, oslam_comm *c, size_t n_local, uint32_t lmax, int rc_local,
+                          uint32_t *gmax_out, size_t *total_out)
 {
-    ncclUniqueId id;
-    ncclResult_t r;
-    if (!id_out) return fail(OSLAM_E_INVALID, "id_out is NULL");
-    r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId");
-    memcpy(id_out, &id, OSLAM_COMM_ID_BYTES);
-    return OSLAM_OK;
-}
-
-void oslam_comm_destroy(oslam_comm *c)
-{
-    if (!c) return;
-    (void)hipSetDevice(c->dev);
-    if (c->nccl) (void)ncclCommDestroy(c->nccl);
-    if (c->d_small) (void)hipFree(c->d_small);
-    free(c->h_small);
-    free(c);
-}
-
-int oslam_comm_create(const void *id, int rank, int world, int dev, oslam_comm **out)
-{
-    int rc = OSLAM_OK;
-    oslam_comm *c;
-    ncclUniqueId uid;
-    if (!out) return fail(OSLAM_E_INVALID, "out is NULL");
-    *out = NULL;
-    if (!id || world < 1 || rank < 0 || rank >= world) return fail(OSLAM_E_INVALID, "bad communicator arguments");
-    if (sizeof(ncclUniqueId) != OSLAM_COMM_ID_BYTES) return fail(OSLAM_E_DEVICE, "ncclUniqueId is not 128 bytes in this RCCL");
-    c = (oslam_comm *)calloc(1, sizeof *c);
-    if (!c) return fail(OSLAM_E_NOMEM, "host allocation failed");
-    c->rank = rank;
-    c->world = world;
-    rc = pick_device(dev, &c->dev);
+    int rc = OSLAM_OK, r, any = 0, grow_any = 0, together = 0;   /* together: every rank leaves at this point */
+    uint32_t n_mine = 0, err, gmax;
+    size_t total = 0, bytes[64];
+    size_t *by = bytes;
+    hipStream_t st = (hipStream_t)g_stream;
+    uint32_t *h = c->h_small, *d = c->d_small;
+    *gmax_out = 0;
+    *total_out = 0;
+    if (c->world > 64) {
+        by = (size_t *)malloc(sizeof(size_t) * (size_t)c->world);
+        if (!by) { by = bytes; rc_local = rc_local != OSLAM_OK ? rc_local : fail(OSLAM_E_NOMEM, "host allocation failed"); }
+    }
+    /* 1. the threshold is global (model.cu:164-170): maximum over ranks, with the error word */
+    h[0] = lmax;
+    h[1] = (rc_local != OSLAM_OK || c->inject_stage == OSLAM_STAGE_VOTE) ? 1u : 0u;
+    HIPCHK(hipMemcpyAsync(d, h, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    rc = oslam_comm_all_reduce_max(c, d, 2, g_stream);
     if (rc != OSLAM_OK) goto done;
-    memcpy(&uid, id, sizeof uid);
-    NCCLCHK(ncclCommInitRank(&c->nccl, world, uid, rank));
-    HIPCHK(hipMalloc((void **)&c->d_small, sizeof(uint32_t) * (size_t)(2 + world)));
-    c->h_small = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(2 + world));
-    if (!c->h_small) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
+    HIPCHK(hipMemcpyAsync(h, d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h[1]) {
+        together = 1;
+        rc = rc_local != OSLAM_OK ? rc_local : c->inject_stage == OSLAM_STAGE_VOTE ? fail(OSLAM_E_DEVICE, "injected failure (vote stage)") : peer_failed();
+        goto done;
+    }
+    gmax = h[0];
+    /* 2. survivors of this rank, compacted into the second record buffer */
+    err = 0;
+    {
+        scratch_pool *pool = pool_lock(m->dev);          /* the selection shares the device's work space */
+        if (!pool || ensure_union(m, n_local > 0 ? n_local : 1) != OSLAM_OK) err = 1;
+        else if (n_local) {
+            const int k = oslamk_select_cells(m->d_out, (uint32_t)n_local, m->params.vote_count_threshold * (float)gmax, m->d_union,
+                                              &n_mine, g_stream);
+            if (k != 0) { (void)fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); err = 1; }
+        }
+        pool_unlock(pool);
+    }
+    if (c->inject_stage == OSLAM_STAGE_SELECT) err = 1;
+    h[0] = n_mine;
+    h[1] = err;
+    h[2] = m->out_cap;
+    HIPCHK(hipMemcpyAsync(d, h, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    rc = oslam_comm_all_gather(c, d, d + 4, 3, g_stream);
+    if (rc != OSLAM_OK) goto done;
+    HIPCHK(hipMemcpyAsync(h + 4, d + 4, 3 * sizeof(uint32_t) * (size_t)c->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (r = 0; r < c->world; r++) {
+        total += h[4 + 3 * r];
+        any |= h[4 + 3 * r + 1] != 0;
+        by[r] = (size_t)h[4 + 3 * r] * sizeof(oslamk_cell);
+    }
+    if (any) {
+        together = 1;
+        rc = err ? (c->inject_stage == OSLAM_STAGE_SELECT ? fail(OSLAM_E_DEVICE, "injected failure (selection stage)")
+                                                           : fail(OSLAM_E_NOMEM, "no device memory for this rank's survivors"))
+                 : peer_failed();
+        goto done;
+    }
+    if (total > ((size_t)1 << 28)) {                       /* the same on every rank */
+        together = 1;
+        rc = fail(OSLAM_E_LIMIT, "more than 2^28 accumulator peaks above the threshold");
+        goto done;
+    }
+    /* 3. room for the union, rank after rank, in m->d_out (this rank's survivors are safe in d_union).  Buffers
+     * differ per rank; whether ANY rank has to grow is known to all from the gathered capacities, and only
+     * then does everybody meet once more to learn whether the growing worked */
+    for (r = 0; r < c->world; r++) grow_any |= total > h[4 + 3 * r + 2];
+    if (grow_any) {
+        err = 0;
+        if (total > m->out_cap && grow_records(m, total + total / 8 + 1024) != OSLAM_OK) err = 1;
+        if (c->inject_stage == OSLAM_STAGE_GROW) err = 1;
+        h[0] = err;
+        HIPCHK(hipMemcpyAsync(d, h, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        rc = oslam_comm_all_reduce_max(c, d, 1, g_stream);
+        if (rc != OSLAM_OK) goto done;
+        HIPCHK(hipMemcpyAsync(h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h[0]) {
+            together = 1;
+            rc = err ? (c->inject_stage == OSLAM_STAGE_GROW ? fail(OSLAM_E_DEVICE, "injected failure (growing the record buffer)")
+                                                             : fail(OSLAM_E_NOMEM, "no memory for the union of the accumulator peaks"))
+                     : peer_failed();
+            goto done;
+        }
+    }
+    /* 4. the union */
+    if (total) {
+        rc = oslam_comm_all_gather_v(c, m->d_union, m->d_out, by, g_stream);
+        if (rc != OSLAM_OK) goto done;
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    *gmax_out = gmax;
+    *total_out = total;
 done:
-    if (rc != OSLAM_OK) { oslam_comm_destroy(c); return rc; }
-    *out = c;
-    return OSLAM_OK;
+    if (rc != OSLAM_OK && !together && !c->broken) {
+        /* a HIP call of this rank failed between collectives: the peers cannot be told through a device buffer any
+         * more; give the communicator up so that nothing of it is used again */
+        c->ops->abort(c->ctx, c->rank);
+        c->broken = 1;
+    }
+    c->inject_stage = OSLAM_STAGE_NONE;
+    if (by != bytes) free(by);
+    return rc;
 }
 
 int oslam_align_multi(oslam_model *m, oslam_scene *s, oslam_comm *c, float T[16], oslam_stats *stats)
 {
-    int rc, r;
+    int rc, vrc;
     oslamk_counters cnt;
     size_t n = 0, total = 0;
-    uint32_t gmax, n_mine = 0;
+    uint32_t gmax = 0;
     oslam_stats local;
     scratch_pool *pool = NULL;
-    hipStream_t st = (hipStream_t)g_stream;
     double t0 = now_ms();
     if (!T || !c) return fail(OSLAM_E_INVALID, "NULL argument");
     memset(T, 0, 16 * sizeof(float));
@@ -1807,67 +1882,42 @@ int oslam_align_multi(oslam_model *m, oslam_scene *s, oslam_comm *c, float T[16]
     if (rc != OSLAM_OK) return rc;
     if (c->dev != m->dev) return fail(OSLAM_E_INVALID, "communicator and model live on different devices");
     if (s->world != c->world || s->rank != c->rank) return fail(OSLAM_E_INVALID, "the scene's shard differs from the communicator's rank");
+    if (c->broken) return fail(OSLAM_E_DEVICE, "the communicator was aborted after a failed collective: make a new one");
     if (!stats) stats = &local;
     memset(stats, 0, sizeof *stats);
     if (hipSetDevice(m->dev) != hipSuccess) return fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    /* this rank's votes; the records stay in m->d_out.  The device's pool is held for the votes and for the pose
+     * tail, not across the collectives: emulated ranks share a device (and a pool) */
+    memset(&cnt, 0, sizeof cnt);
     pool = pool_lock(m->dev);
-    if (!pool) return fail(OSLAM_E_LIMIT, "device ordinal too large");
-    g_cur_pool = pool;
-    /* this rank's votes; the records stay in m->d_out */
-    rc = vote_and_fetch(pool, m, s, &cnt, &n, stats, 1);
+    if (!pool) vrc = fail(OSLAM_E_LIMIT, "device ordinal too large");
+    else {
+        g_cur_pool = pool;
+        vrc = vote_and_fetch(pool, m, s, &cnt, &n, stats, 1);
+        g_cur_pool = NULL;
+        pool_unlock(pool);
+    }
+    if (vrc != OSLAM_OK) { n = 0; cnt.gmax = 0; }
+    rc = exchange_peaks(m, c, n, cnt.gmax, vrc, &gmax, &total);
     if (rc != OSLAM_OK) goto done;
-    /* the threshold is global (model.cu:164-170): maximum over ranks */
-    c->h_small[0] = cnt.gmax;
-    HIPCHK(hipMemcpyAsync(c->d_small, c->h_small, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    NCCLCHK(ncclAllReduce(c->d_small, c->d_small, 1, ncclUint32, ncclMax, c->nccl, st));
-    HIPCHK(hipMemcpyAsync(&gmax, c->d_small, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    /* survivors of this rank, compacted into the second record buffer */
-    rc = ensure_union(m, n > 0 ? n : 1);
-    if (rc != OSLAM_OK) goto done;
-    if (n) {
-        const int k = oslamk_select_cells(m->d_out, (uint32_t)n, m->params.vote_count_threshold * (float)gmax, m->d_union,
-                                          &n_mine, g_stream);
-        if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
-    }
-    c->h_small[1] = n_mine;
-    HIPCHK(hipMemcpyAsync(c->d_small + 1, c->h_small + 1, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    NCCLCHK(ncclAllGather(c->d_small + 1, c->d_small + 2, 1, ncclUint32, c->nccl, st));
-    HIPCHK(hipMemcpyAsync(c->h_small + 2, c->d_small + 2, sizeof(uint32_t) * (size_t)c->world, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (r = 0; r < c->world; r++) total += c->h_small[2 + r];
-    if (total > ((size_t)1 << 28)) { rc = fail(OSLAM_E_LIMIT, "more than 2^28 accumulator peaks above the threshold"); goto done; }
-    /* the union, rank after rank, in m->d_out (grown if needed; this rank's survivors are safe in d_union) */
-    if (total > m->out_cap) {
-        rc = grow_records(m, total + total / 8 + 1024);
-        if (rc != OSLAM_OK) goto done;
-    }
-    if (total) {
-        size_t off = 0;
-        NCCLCHK(ncclGroupStart());
-        for (r = 0; r < c->world; r++) {
-            const size_t nr = c->h_small[2 + r];
-            if (nr) {
-                ncclResult_t br = ncclBroadcast(m->d_union, m->d_out + off, nr * sizeof(oslamk_cell), ncclUint8, r, c->nccl, st);
-                if (br != ncclSuccess) { (void)ncclGroupEnd(); rc = nccl_fail(br, "ncclBroadcast"); goto done; }
-            }
-            off += nr;
-        }
-        NCCLCHK(ncclGroupEnd());
-        HIPCHK(hipStreamSynchronize(st));
-    }
     stats->num_emitted = (uint32_t)total;
     /* every rank finishes on the same union: same pose everywhere, no second exchange */
+    pool = pool_lock(m->dev);
+    g_cur_pool = pool;
     if (pose_gpu_from(m) && total >= pose_gpu_from(m)) {
         int done = 0;
         rc = finish_on_device(m, s, total, gmax, T, stats, &done);
-        if (rc != OSLAM_OK || done) goto done;
+        if (rc != OSLAM_OK || done) goto unlock;
     }
-    if (total) HIPCHK(hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * total, hipMemcpyDeviceToHost));
+    if (total && hipMemcpy(m->h_out, m->d_out, sizeof(oslam_cell) * total, hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = fail(OSLAM_E_DEVICE, "hipMemcpy of the union failed");
+        goto unlock;
+    }
     rc = finish_cells(m, s, m->h_out, total, gmax, T, stats);
-done:
+unlock:
     g_cur_pool = NULL;
     pool_unlock(pool);
+done:
     stats->ms_total = (float)(now_ms() - t0);
     return rc;
 }
@@ -1899,21 +1949,34 @@ static int same_group(const oslam_model *a, const oslam_model *b)
     return a->dev == b->dev && a->d_dist == b->d_dist && a->params.vote_mode == b->params.vote_mode;
 }
 
-void oslam_db_destroy(oslam_db *db)
+static void db_destroy(oslam_db *db, int give_back)
 {
     int g, k;
     uint32_t *d_small = NULL;
     if (!db) return;
     (void)hipSetDevice(db->dev);
-    (void)hipMalloc((void **)&d_small, 2 * sizeof(uint32_t));
+    if (give_back) (void)hipMalloc((void **)&d_small, 2 * sizeof(uint32_t));
     for (g = 0; g < db->n_groups; g++) {
         db_group *gr = &db->groups[g];
         if (gr->n > 1) {
-            /* the members get a union table of their own back */
+            /* the members get a union table of their own back; one that cannot (or is not asked to) is left
+             * without key tables and refuses every call but oslam_model_destroy */
             for (k = 0; k < gr->n; k++) {
                 oslam_model *m = db->models[gr->members[k]];
+                int ok = 0;
+                if (!m->shared_union) continue;         /* never switched to the group's tables (a failed oslam_db_create) */
                 if (d_small && build_union(m, (uint32_t)(m->num_model_keys ? m->num_model_keys - 1 : 0), d_small, d_small + 1) == OSLAM_OK)
-                    (void)build_uinfo(m);
+                    ok = build_uinfo(m) == OSLAM_OK;
+                if (!ok) {
+                    if (m->shared_union) {               /* still pointing at the group's tables, which are freed below */
+                        m->table.ukeys = NULL;
+                        m->table.reach = NULL;
+                        m->table.kmap = NULL;
+                        m->table.uids = NULL;
+                        m->shared_union = 0;
+                    }
+                    m->unusable = 1;
+                }
             }
             (void)hipStreamSynchronize((hipStream_t)g_stream);
             if (gr->ukeys) (void)hipFree(gr->ukeys);
@@ -1929,6 +1992,10 @@ void oslam_db_destroy(oslam_db *db)
     free(db);
 }
 
+void oslam_db_destroy(oslam_db *db) { db_destroy(db, 1); }
+
+void oslam_db_destroy_with_models(oslam_db *db) { db_destroy(db, 0); }
+
 int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
 {
     int rc = OSLAM_OK, g, k;
@@ -1941,7 +2008,10 @@ int oslam_db_create(oslam_model *const *models, size_t n, oslam_db **out)
     for (j = 0; j < n; j++) {
         if (!models[j]) return fail(OSLAM_E_INVALID, "NULL model");
         if (models[j]->shared_union) return fail(OSLAM_E_INVALID, "a model can be in one database at a time");
+        if (models[j]->unusable) return fail(OSLAM_E_INVALID, "a model without key tables cannot join a database");
         if (models[j]->dev != models[0]->dev) return fail(OSLAM_E_INVALID, "the models of a database live on one device");
+        for (k = 0; k < (int)j; k++)
+            if (models[k] == models[j]) return fail(OSLAM_E_INVALID, "the same model handle twice in one database");
     }
     db = (oslam_db *)calloc(1, sizeof *db);
     if (!db) return fail(OSLAM_E_NOMEM, "host allocation failed");
@@ -2113,6 +2183,75 @@ int oslam_db_size(const oslam_db *db, size_t *n_models, size_t *n_groups)
     return OSLAM_OK;
 }
 
+/* The database split by model (see oslam.h): this rank's models against the whole scene, then every pose to every
+ * rank in one all-gather of {found, error, 16 floats} per model slot.  An error on one rank travels in its slots'
+ * error word: every rank returns (OSLAM_E_PEER on the others). */
+int oslam_db_align_multi(oslam_db *db, oslam_scene *s, oslam_comm *c, size_t n_total, float *T_out, int *found_out,
+                         oslam_stats *stats_local)
+{
+    int rc = OSLAM_OK, lrc = OSLAM_OK, any = 0, r;
+    size_t n_mine, block, k, words;
+    uint32_t *h_send = NULL, *h_recv = NULL, *d_buf = NULL;
+    float *T_loc = NULL;
+    hipStream_t st = (hipStream_t)g_stream;
+    if (!s || !c || !T_out || n_total == 0) return fail(OSLAM_E_INVALID, "NULL argument");
+    if (c->broken) return fail(OSLAM_E_DEVICE, "the communicator was aborted after a failed collective: make a new one");
+    if (s->world != 1) return fail(OSLAM_E_INVALID, "a database split by model takes the whole scene on every rank (shard_world 1)");
+    n_mine = (n_total + (size_t)c->world - 1 - (size_t)c->rank) / (size_t)c->world;     /* models rank, rank + world, ... */
+    block = (n_total + (size_t)c->world - 1) / (size_t)c->world;
+    if ((db ? db->n : 0) != n_mine) return fail(OSLAM_E_INVALID, "this rank's database does not hold models rank, rank + world, ... of n_total");
+    memset(T_out, 0, sizeof(float) * 16 * n_total);
+    if (found_out) memset(found_out, 0, sizeof(int) * n_total);
+    words = 18 * block;
+    h_send = (uint32_t *)calloc(words ? words : 1, sizeof(uint32_t));
+    h_recv = (uint32_t *)malloc(sizeof(uint32_t) * (words ? words : 1) * (size_t)c->world);
+    T_loc = (float *)calloc(16 * (n_mine ? n_mine : 1), sizeof(float));
+    if (!h_send || !h_recv || !T_loc) lrc = fail(OSLAM_E_NOMEM, "host allocation failed");
+    if (hipSetDevice(c->dev) != hipSuccess) lrc = fail(OSLAM_E_DEVICE, "hipSetDevice failed");
+    if (lrc == OSLAM_OK && n_mine) lrc = oslam_db_align(db, s, T_loc, stats_local);
+    if (lrc == OSLAM_OK && hipMalloc((void **)&d_buf, sizeof(uint32_t) * words * (size_t)(c->world + 1)) != hipSuccess) {
+        d_buf = NULL;
+        lrc = fail(OSLAM_E_NOMEM, "no device memory for the pose exchange");
+    }
+    if (!h_send || !h_recv || !d_buf) {          /* cannot even take part in the collective: the communicator is given up */
+        if (!c->broken) { c->ops->abort(c->ctx, c->rank); c->broken = 1; }
+        rc = lrc;
+        goto done;
+    }
+    for (k = 0; k < block; k++) {
+        uint32_t *slot = h_send + 18 * k;
+        slot[1] = lrc != OSLAM_OK;
+        if (k < n_mine && lrc == OSLAM_OK) {
+            int nz = 0, q;
+            for (q = 0; q < 16; q++) nz |= T_loc[16 * k + q] != 0.0f;
+            slot[0] = (uint32_t)nz;             /* a model without votes leaves its pose all zeros */
+            memcpy(slot + 2, T_loc + 16 * k, 16 * sizeof(float));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(d_buf, h_send, sizeof(uint32_t) * words, hipMemcpyHostToDevice, st));
+    rc = oslam_comm_all_gather(c, d_buf, d_buf + words, words, g_stream);
+    if (rc != OSLAM_OK) goto done;
+    HIPCHK(hipMemcpyAsync(h_recv, d_buf + words, sizeof(uint32_t) * words * (size_t)c->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (r = 0; r < c->world; r++)
+        for (k = 0; k < block; k++) any |= h_recv[((size_t)r * block + k) * 18 + 1] != 0;
+    if (any) { rc = lrc != OSLAM_OK ? lrc : peer_failed(); goto done; }
+    for (r = 0; r < c->world; r++)
+        for (k = 0; k < block; k++) {
+            const size_t j = k * (size_t)c->world + (size_t)r;
+            const uint32_t *slot = h_recv + ((size_t)r * block + k) * 18;
+            if (j >= n_total) continue;
+            memcpy(T_out + 16 * j, slot + 2, 16 * sizeof(float));
+            if (found_out) found_out[j] = (int)slot[0];
+        }
+done:
+    free(h_send);
+    free(h_recv);
+    free(T_loc);
+    if (d_buf) (void)hipFree(d_buf);
+    return rc;
+}
+
 int oslam_ppf_registration(const float *const *scene_xyz, const float *const *scene_nrm,
                            const size_t *scene_n, size_t n_scenes, const float *const *model_xyz,
                            const float *const *model_nrm, const size_t *model_n, size_t n_models,
@@ -2152,7 +2291,7 @@ int oslam_ppf_registration(const float *const *scene_xyz, const float *const *sc
         if (rc == OSLAM_OK) rc = oslam_db_align(db, sc, T_out + 16 * (i * n_models), NULL);
         oslam_scene_destroy(sc);
     }
-    oslam_db_destroy(db);
+    oslam_db_destroy_with_models(db);         /* the models go next: no key tables are rebuilt for them */
     for (j = 0; j < n_models; j++) oslam_model_destroy(models[j]);
     free(models);
     return rc;

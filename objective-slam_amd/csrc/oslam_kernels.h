@@ -99,7 +99,9 @@ typedef struct oslamk_counters {
     uint32_t redo_total;          /* the same, summed over the launches of a call */
     unsigned long long entries;   /* model pair entries streamed: sum of the bucket lengths over (run, slice) */
     unsigned long long items;     /* (run, slice) pairs with a bucket */
-    unsigned long long prof[4];   /* -DVOTE_PROF builds: k_vote wave cycles (end of voting, barrier, peak extraction, vote steps) */
+    unsigned long long prof[4];   /* -DVOTE_PROF builds: k_vote wave cycles (pre-scan, voting, wait at the barrier behind it, peak extraction) */
+    uint32_t list_overflow;       /* a hit list was too short for its hits (the counting and the hit kernel disagreed): the call fails */
+    uint32_t pad_;
 } oslamk_counters;
 
 typedef struct oslamk_cell {

@@ -807,11 +807,17 @@ __device__ __forceinline__ void hits_chunk(const oslamk_vote_args &a, int ref_lo
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&a.hit_count[ref_local], (uint32_t)__popcll(hm));
         base = readlane_u(base, 0);
-        if (hit) {
-            const size_t pos = (size_t)a.hit_off[ref_local] + base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        /* The list has as many places as k_scene_count found pairs within reach, by the same predicate as phase 1
+         * here -- checked, not assumed: a hit that would not fit is dropped and flagged, and the host turns the flag
+         * into an error instead of using lists that ran into their neighbours. */
+        const uint32_t cap = a.hit_off[ref_local + 1] - a.hit_off[ref_local];
+        const uint32_t at = base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        if (hit && at < cap) {
+            const size_t pos = (size_t)a.hit_off[ref_local] + at;
             a.hit_key[pos] = slot;
             a.hit_pay[pos] = pay;
         }
+        if (lane == 0 && base + (uint32_t)__popcll(hm) > cap) atomicOr(&a.counters->list_overflow, 1u);
     }
 }
 
@@ -1015,6 +1021,9 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
     }
     const uint32_t n_q = uni_u32(s_qn);
     T = uni_u32(T);
+#ifdef VOTE_PROF
+    const long long ptA = clock64();
+#endif
 
     /* A counter word of the accumulator holds two 16-bit counters (two model reference points per row: a slice of
      * 2046 fits the 128 KiB).  PASS 0 -- the kernel every registration runs -- votes into both at once.  A counter
@@ -1217,9 +1226,10 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
         __syncthreads();
 #ifdef VOTE_PROF
         const long long pt2 = clock64();
-        if (lane == 0) {
-            atomicAdd(&a.counters->prof[0], (unsigned long long)(pt1 - pt0));
-            atomicAdd(&a.counters->prof[1], (unsigned long long)(pt2 - pt0));
+        if (lane == 0) {             /* wave cycles: pre-scan (with zeroing), voting, wait at the barrier behind it */
+            atomicAdd(&a.counters->prof[0], (unsigned long long)(ptA - pt0));
+            atomicAdd(&a.counters->prof[1], (unsigned long long)(pt1 - ptA));
+            atomicAdd(&a.counters->prof[2], (unsigned long long)(pt2 - pt1));
         }
 #endif
 
@@ -1256,6 +1266,9 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
             }
             /* every vote cast is in a counter unless a 16-bit counter overflowed */
             s_redo = pass == 0 && tot != s_tot[0] - s_ctx.dropped;
+#if defined(VOTE_DIAG_NOLOOP) || defined(VOTE_DIAG_NOATOM)
+            s_redo = 0;                 /* timing-only builds cast no votes: nothing to check */
+#endif
             if (s_redo) {
                 a.redo[atomicAdd(&a.counters->redo_count, 1u)] = wg;
                 atomicAdd(&a.counters->redo_total, 1u);
@@ -1349,6 +1362,9 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
                 }
             }
         }
+#ifdef VOTE_PROF
+        if (lane == 0) atomicAdd(&a.counters->prof[3], (unsigned long long)(clock64() - pt2));     /* peak extraction */
+#endif
     }
 }
 

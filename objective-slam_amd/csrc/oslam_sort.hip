@@ -130,8 +130,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
     __shared__ uint32_t s_part[SORT_THREADS / WAVE];
     __shared__ uint32_t s_last[SORT_THREADS];           /* the last key of every thread's sorted positions */
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-    const uint32_t n_all = a.hit_count[ref_local];
     const size_t off = a.hit_off[ref_local];
+    const uint32_t cap = a.hit_off[ref_local + 1] - a.hit_off[ref_local];
+    const uint32_t n_all = a.hit_count[ref_local] < cap ? a.hit_count[ref_local] : cap;     /* never past the list (oslamk_counters.list_overflow) */
     const unsigned bits = a.table.id_bits;
     uint32_t n_runs = 0;                /* the same value in every thread */
     for (uint32_t seg = 0; seg < n_all; seg += SORT_MAX) {

@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OSLAM_LIB", os.path.join(_HERE, "liboslam_hip.so"))   # OSLAM_LIB: A/B builds
 _LIB = None
 
-OSLAM_OK, OSLAM_E_INVALID, OSLAM_E_DEVICE, OSLAM_E_NOMEM, OSLAM_E_NO_VOTES, OSLAM_E_LIMIT = range(6)
+OSLAM_OK, OSLAM_E_INVALID, OSLAM_E_DEVICE, OSLAM_E_NOMEM, OSLAM_E_NO_VOTES, OSLAM_E_LIMIT, OSLAM_E_PEER = range(7)
+STAGE_VOTE, STAGE_SELECT, STAGE_GROW = 1, 2, 3       # oslam_comm_inject_failure
 VOTE_EXACT, VOTE_FAST = 0, 1
 COMM_ID_BYTES = 128
 
@@ -34,7 +35,8 @@ class Params(C.Structure):
     _fields_ = [("ref_point_df", C.c_uint), ("vote_count_threshold", C.c_float),
                 ("cpu_clustering", C.c_int), ("use_l1_norm", C.c_int), ("use_averaged_clusters", C.c_int),
                 ("dev", C.c_int), ("vote_mode", C.c_int), ("shard_rank", C.c_int), ("shard_world", C.c_int),
-                ("max_cells", C.c_uint), ("reserved", C.c_int * 6)]
+                ("max_cells", C.c_uint), ("pose_gpu_min", C.c_uint), ("no_bucket_spread", C.c_int),
+                ("scratch_gib", C.c_uint), ("reserved", C.c_int * 3)]
 
 
 class Stats(C.Structure):
@@ -87,6 +89,12 @@ _SIGNATURES = {
     "oslam_comm_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     "oslam_comm_destroy": (None, [_vp]),
     "oslam_align_multi": (_i, [_vp, _vp, _vp, _vp, C.POINTER(Stats)]),
+    "oslam_comm_create_loopback": (_i, [_i, _i, C.POINTER(_vp)]),
+    "oslam_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "oslam_comm_inject_failure": (_i, [_vp, _i]),
+    "oslam_comm_abort": (_i, [_vp]),
+    "oslam_db_align_multi": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "oslam_db_destroy_with_models": (None, [_vp]),
     "oslam_release_scratch": (_i, [_i]),
     "oslam_db_create": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "oslam_db_destroy": (None, [_vp]),
@@ -130,10 +138,15 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# Fields every default_params() call starts from, on top of the library's defaults: how tests and tools steer
+# library-wide switches (pose_gpu_min, scratch_gib ...) -- through oslam_params, not through the environment.
+DEFAULT_OVERRIDES = {}
+
+
 def default_params(**kw):
     p = Params()
     _check(lib().oslam_params_default(C.byref(p)))
-    for k, v in kw.items():
+    for k, v in {**DEFAULT_OVERRIDES, **kw}.items():
         if not hasattr(p, k):
             raise TypeError("unknown parameter %r" % k)
         setattr(p, k, v)
@@ -425,6 +438,11 @@ class Database:
             m.best_T, m.stats = t, d
         return T, stats
 
+    def align_multi(self, scene, comm, n_total):
+        """This rank's models (j = rank, rank + world, ... of n_total) against the whole scene, then every pose to
+        every rank through the communicator (oslam_db_align_multi).  -> (poses [n_total,4,4], found [n_total])."""
+        return db_align_multi(self, scene, comm, n_total)
+
     def close(self):
         if self._h:
             lib().oslam_db_destroy(self._h)
@@ -439,15 +457,50 @@ class Database:
             pass
 
 
-class Comm:
-    """RCCL communicator of the multi-GPU path (oslam_comm): rank 0 makes the id, everybody gets its bytes
-    (here: through torch.distributed, any backend) and creates its end."""
+def db_align_multi(db, scene, comm, n_total):
+    """oslam_db_align_multi; db may be None on a rank that holds no model."""
+    T = np.zeros((int(n_total), 4, 4), np.float32)
+    found = np.zeros(int(n_total), np.int32)
+    n_mine = len(db.models) if db is not None else 0
+    st = (Stats * max(1, n_mine))()
+    _check(lib().oslam_db_align_multi(db._h if db is not None else None, scene._h, comm._h, int(n_total), _p(T), _p(found), st))
+    if db is not None:
+        for m, d in zip(db.models, st):
+            m.stats = d.asdict()
+    return T, found
 
-    def __init__(self, id_bytes, rank, world, dev):
+
+class Comm:
+    """Communicator of the multi-GPU path (oslam_comm).  RCCL: rank 0 makes the id, everybody gets its bytes
+    (here: through torch.distributed, any backend) and creates its end.  Comm.loopback(world): `world` emulated
+    ranks on one device inside this process, one thread per rank -- the same exchange code, for tests."""
+
+    def __init__(self, id_bytes, rank, world, dev, _handle=None):
         self._h = C.c_void_p(0)
+        self.rank, self.world = rank, world
+        if _handle is not None:
+            self._h = C.c_void_p(_handle)
+            return
         buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
         _check(lib().oslam_comm_create(buf, int(rank), int(world), int(dev), C.byref(self._h)))
-        self.rank, self.world = rank, world
+
+    @classmethod
+    def loopback(cls, world, dev=0):
+        arr = (C.c_void_p * int(world))()
+        _check(lib().oslam_comm_create_loopback(int(world), int(dev), arr))
+        return [cls(None, r, int(world), dev, _handle=arr[r]) for r in range(int(world))]
+
+    def abort(self):
+        _check(lib().oslam_comm_abort(self._h))
+
+    def inject_failure(self, stage):
+        _check(lib().oslam_comm_inject_failure(self._h, int(stage)))
+
+    @property
+    def broken(self):
+        b = C.c_int(0)
+        _check(lib().oslam_comm_info(self._h, None, None, C.byref(b)))
+        return bool(b.value)
 
     @staticmethod
     def unique_id():

@@ -59,7 +59,57 @@ def make_case(name, M, S, seed, df, tau_d=0.05, model_id=0):
     print(name, "cells", len(cells), "stats", st)
 
 
+def make_fullsize_case(name="case_5k_100k_df8", M=5000, S=100000, df=8, tau_d=0.025, seed=2002, threads=0, chunks=50):
+    """The bench workload itself (bench.py: model 0 at 5000 points, scene seed 2002 at 100000 points with one
+    instance, noise 0.1 d_dist, ref_point_df 8): the oracle's whole registration -- 12 500 reference points,
+    1.9e11 votes, about 10 minutes of 16 host threads.  Run in interleaved chunks of reference points (so that a
+    progress line appears every few seconds and every chunk's maximum is close to the global one); the chunks' peak
+    cells are supersets of what survives the global threshold (model.cu:164-170), so their union filtered with the
+    global maximum and ordered (count desc, code asc) is the single run's list.
+        python tests/golden/make_golden.py fullsize [threads]"""
+    import hashlib
+    import time
+    mp, mn = synth.make_model(0, M)
+    d = synth.d_dist_for(mp, tau_d)
+    sp, sn, poses = synth.make_scene([0], S, seed, instance_points=M, noise_sigma=0.1 * d)
+    fm = O.FusedModel(mp, mn, d)
+    parts, tot = [], {k: 0 for k in ("num_scene_ppfs", "num_hits", "num_votes", "num_unique_votes")}
+    gmax, t0 = 0, time.time()
+    for c in range(chunks):
+        cells, st = fm.votes(sp, sn, df, thresh=0.4, ref_begin=c, ref_step=chunks, threads=threads)
+        parts.append(cells)
+        for k in tot:
+            tot[k] += st[k]
+        gmax = max(gmax, st["max_count"])
+        print("chunk %d/%d: %d cells, max %d, %.0f s" % (c + 1, chunks, len(cells), st["max_count"], time.time() - t0), flush=True)
+    num_model_keys = st["num_model_keys"]
+    fm.close()
+    allc = np.concatenate(parts)
+    keep = allc[allc["count"].astype(np.float32) > np.float32(0.4) * np.float32(gmax)]      # model.cu:164-167, in float
+    keep = keep[np.lexsort((keep["code"], -keep["count"].astype(np.int64)))]
+    out = {}
+    for tag, kw in (("gpu", {}), ("cpu", {"cpu_clustering": True}), ("avg", {"use_averaged_clusters": True})):
+        rc, T = O.pose_from_cells(keep, mp, mn, sp, sn, d, **kw)
+        out["T_" + tag] = T
+    poses_all = O.trans_calc2(keep, mp, mn, sp, sn)
+    h = hashlib.sha256()
+    for a in (mp, mn, sp, sn):
+        h.update(np.ascontiguousarray(a, np.float32).tobytes())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), clouds_sha256=np.array(h.hexdigest()), d_dist=np.float32(d),
+                        df=np.int32(df), M=np.int32(M), S=np.int32(S), tau_d=np.float32(tau_d), seed=np.int32(seed),
+                        cell_code=keep["code"], cell_count=keep["count"],
+                        poses_sha256=np.array(hashlib.sha256(poses_all.tobytes()).hexdigest()),
+                        truth=poses[0][1].astype(np.float64),
+                        stats=np.array([tot["num_scene_ppfs"], tot["num_hits"], tot["num_votes"], tot["num_unique_votes"],
+                                        num_model_keys, gmax, len(keep)], np.uint64),
+                        oracle_seconds=np.float32(time.time() - t0), **out)
+    print(name, "cells", len(keep), "gmax", gmax, "stats", tot)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        make_fullsize_case(threads=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
     with open(os.path.join(HERE, "survey_known_answers.json"), "w") as f:
         json.dump(SURVEY, f, indent=1)
     make_case("case_m64_s128", 64, 128, 3001, 1)

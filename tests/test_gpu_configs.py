@@ -335,13 +335,11 @@ def test_align_multi_on_a_communicator_of_one(ppf, oracle, built_lib, case_small
     """oslam_align_multi through RCCL with a world of one rank (all this box has): the all-reduce of the maximum, the
     device-side filter with the global threshold, the all-gather with exact sizes and the pose tail on the union
     give the single-GPU registration -- cells, counters and pose -- with the host tail and with the device tail."""
-    import os
     comm = ppf.Comm(ppf.Comm.unique_id(), 0, 1, 0)
     try:
         for c, df in ((case_small, 1), (case_two_slices, 10)):
-            for tail_min in ("2", "1000000"):
-                os.environ["OSLAM_POSE_GPU_MIN"] = tail_min
-                mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"])
+            for tail_min in (2, 1000000):
+                mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], params=ppf.default_params(pose_gpu_min=tail_min))
                 sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=df)
                 T1 = mo.ppf_lookup(sc).copy()
                 cells1, st1 = mo.last_cells()[0], dict(mo.stats)
@@ -353,7 +351,6 @@ def test_align_multi_on_a_communicator_of_one(ppf, oracle, built_lib, case_small
                 assert cells_equal(cells1, ocells)
                 mo.close()
     finally:
-        os.environ.pop("OSLAM_POSE_GPU_MIN", None)
         comm.close()
     # a scene whose shard is not the communicator's rank is refused
     par = ppf.default_params(shard_rank=1, shard_world=2)

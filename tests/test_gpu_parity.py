@@ -586,7 +586,8 @@ def test_depth_frame_to_pose(ppf, built_lib, synth):
 @pytest.fixture
 def pose_tail_on_device(monkeypatch):
     # the device pose tail (oslam_posegpu.hip) normally starts at 4096 peak records; run it from 2
-    monkeypatch.setenv("OSLAM_POSE_GPU_MIN", "2")
+    import importlib
+    monkeypatch.setitem(importlib.import_module("objective-slam_amd").ppf.DEFAULT_OVERRIDES, "pose_gpu_min", 2)
 
 
 def test_device_pose_tail_equals_oracle(ppf, oracle, built_lib, case_small, case_two_slices, synth, pose_tail_on_device):

@@ -37,7 +37,8 @@ for t in range(trials):
     print("trial %d kind %d M %d S %d df %d" % (t, kind, len(mp), len(sp), df), flush=True)
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != t:
         continue
-    os.environ["OSLAM_POSE_GPU_MIN"] = os.environ.get("FUZZ_TAIL", "2" if t % 2 else "1000000000")
+    tail = int(os.environ.get("FUZZ_TAIL", "2" if t % 2 else "1000000000"))
+    ppf.DEFAULT_OVERRIDES["pose_gpu_min"] = tail
     flags = {} if t % 5 else dict(use_l1_norm=True)
     try:
         mo = ppf.Model(mp, mn, d_dist=d, vote_count_threshold=thr, **flags)
@@ -56,7 +57,7 @@ for t in range(trials):
         print("trial", t, "exception", repr(e))
     if not ok:
         bad += 1
-        print("MISMATCH trial %d kind %d M %d S %d df %d thr %.1f d %.3f tail %s" % (t, kind, M, S, df, thr, d, os.environ["OSLAM_POSE_GPU_MIN"]), flush=True)
+        print("MISMATCH trial %d kind %d M %d S %d df %d thr %.1f d %.3f tail %s" % (t, kind, M, S, df, thr, d, tail), flush=True)
     mo.close(); sc.close()
     if t % 10 == 9:
         print("trial %d done, %d mismatches so far" % (t + 1, bad), flush=True)

@@ -12,9 +12,8 @@ tau = float(sys.argv[4]) if len(sys.argv) > 4 else 0.04
 mp, mn = synth.make_model(0, M); d = synth.d_dist_for(mp, tau)
 sp, sn, poses = synth.make_scene([0], S, 2051, instance_points=M, noise_sigma=0.1 * d)
 out = {"model_points": M, "scene_points": S, "ref_point_df": df, "tau_d": tau}
-for name, gpu_min in (("host tail", "1000000000"), ("device tail", "2")):
-    os.environ["OSLAM_POSE_GPU_MIN"] = gpu_min
-    mo = ppf.Model(mp, mn, d_dist=d); sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df)
+for name, gpu_min in (("host tail", 1000000000), ("device tail", 2)):
+    mo = ppf.Model(mp, mn, d_dist=d, params=ppf.default_params(pose_gpu_min=gpu_min)); sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df)
     T = mo.ppf_lookup(sc); cells, gposes = mo.last_cells(); st = dict(mo.stats)
     if "oracle" not in out:
         t = time.time(); ocells, ost = O.votes_fused(mp, mn, sp, sn, df, d, 0.4, threads=16); out["oracle_seconds"] = time.time() - t
