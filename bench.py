@@ -39,7 +39,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-KERNEL_SRC = os.path.join(ROOT, "objective-slam_amd", "csrc", "oslam_kernels.hip")
 
 
 def log(*a):
@@ -47,8 +46,8 @@ def log(*a):
 
 
 def kernel_source_hash():
-    with open(KERNEL_SRC, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    import importlib
+    return importlib.import_module("objective-slam_amd").ppf.kernel_source_hash()
 
 
 def main():
@@ -114,15 +113,11 @@ def main():
     # this node the same steps run through host buffers and torch.distributed instead -- on every rank or on none
     comm, exchange = None, "single GPU"
     if world > 1 and backend == "nccl":
-        try:
-            comm = pkg.dist.make_comm(dev_index)
-        except Exception as e:                       # noqa: BLE001 -- reported below, the run goes on
-            log("[rank %d] oslam_comm_create failed (%s): exchange through host buffers" % (rank, e))
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=xdev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
+        # every rank enters the same collectives whatever fails where (dist.make_comm: rank 0 always broadcasts, an id
+        # or None; then the ranks agree on whether all of them have a communicator)
+        comm, why = pkg.dist.make_comm(dev_index)
+        if comm is None:
+            log("[rank %d] no RCCL communicator (%s): exchange through host buffers" % (rank, why))
         exchange = "oslam_align_multi (RCCL inside the library)" if comm is not None else "host buffers + torch.distributed (nccl)"
     elif world > 1:
         exchange = "host buffers + torch.distributed (%s)" % backend
@@ -253,7 +248,10 @@ def main():
             "model_build_s": t_build,
             "roofline": {"bound": "hbm", "kernel": "k_vote", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "measured_against": "design bytes vs the HBM peak; the 100 MB entry stream is served from the "
+                                             "256 MiB Infinity Cache, so this prices the stream, not HBM pins",
                          "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_ratio": (traffic / design_launch) if traffic else None,
                          "alg_bytes_per_launch": design_launch, "launch_ms": per_launch_ms,
                          "launches_per_step": launches / args.steps,
                          "alg_bytes_model": "4 B x model pair entries streamed (each bucket once per run of hits and slice) "
@@ -280,7 +278,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mp, mn, sp, sn, df, d_dist)
-            out["pose_recall_at_1deg"] = pose_recall(ppf, synth, mode)
+            out["pose_recall_at_1deg"] = pose_recall(ppf, synth, mode, T, model.last_cells()[0], args, df)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
@@ -305,7 +303,7 @@ def pmc_traffic(args, M, S, df):
     except (OSError, ValueError):
         return None, "unreadable " + os.path.basename(files[-1])
     if rec.get("kernel_source_sha16") != kernel_source_hash():
-        return None, ("%s was taken with another oslam_kernels.hip (stale): re-run tools/profile_round.sh"
+        return None, ("%s was taken with other kernel sources (stale): re-run tools/profile_round.sh"
                       % os.path.basename(files[-1]))
     for r in rec.get("runs", []):
         if (r["model_points"], r["scene_points"], r["ref_point_df"], r["vote_mode"], r["tau_d"]) == \
@@ -315,12 +313,31 @@ def pmc_traffic(args, M, S, df):
     return None, "no PMC pass for this workload in " + os.path.basename(files[-1])
 
 
-def pose_recall(ppf, synth, mode, trials=6):
-    """Pose recall@1 degree as SURVEY.md 8d defines it: pose of this build vs pose of the CPU
-    restatement on the same clouds, success iff rotation difference < 1 degree and translation
-    difference < 1 % of the model diameter.  The CPU restatement needs hours at 5k x 100k, so the
-    trials are 600-point models in 3000-point scenes (different models, poses and clutter)."""
+FIXTURE = os.path.join(ROOT, "tests", "golden", "case_5k_100k_df8.npz")
+
+
+def pose_recall(ppf, synth, mode, T_bench, cells_bench, args, df, trials=6):
+    """Pose recall@1 degree as SURVEY.md 8d defines it: pose of this build vs pose of the CPU restatement on the same
+    clouds, success iff rotation difference < 1 degree and translation difference < 1 % of the model diameter.
+    The trial that counts is the bench workload itself: the oracle's whole 5k x 100k registration (50 minutes of host
+    threads) is committed as tests/golden/case_5k_100k_df8.npz, and the pose and kept cells of the timed steps are
+    compared with it.  Six small registrations against the oracle run live (different models, poses and clutter)
+    are reported beside it."""
     from oracle import oracle as O
+    out = {"against": "CPU restatement (oracle) on the same clouds"}
+    if (args.model_points, args.scene_points, df, args.tau_d) == (5000, 100000, 8, 0.025) and os.path.exists(FIXTURE):
+        z = np.load(FIXTURE)
+        dt, dr = ppf.ht_dist(T_bench, z["T_gpu"])
+        diam = synth.bbox_extent(synth.make_model(0, args.model_points)[0])
+        ok = bool(np.degrees(dr) < 1.0 and dt < 0.01 * diam)
+        out.update({"trials": 1, "recall": 1.0 if ok else 0.0,
+                    "workload": "the bench workload: 5000-point model, 100000-point scene, ref_point_df 8 (oracle output "
+                                "committed as tests/golden/case_5k_100k_df8.npz)",
+                    "rot_diff_deg": float(np.degrees(dr)), "trans_diff_frac_diam": dt / diam,
+                    "pose_identical": bool(np.array_equal(T_bench, z["T_gpu"])),
+                    "kept_cells_identical": bool(len(cells_bench) == len(z["cell_code"]) and
+                                                 np.array_equal(cells_bench["code"], z["cell_code"]) and
+                                                 np.array_equal(cells_bench["count"], z["cell_count"]))})
     ok = 0
     worst = (0.0, 0.0)
     for k in range(trials):
@@ -334,9 +351,13 @@ def pose_recall(ppf, synth, mode, trials=6):
         dt, dr = ppf.ht_dist(T, To)
         worst = (max(worst[0], float(np.degrees(dr))), max(worst[1], dt / synth.bbox_extent(m_p)))
         ok += int(np.degrees(dr) < 1.0 and dt < 0.01 * synth.bbox_extent(m_p))
-    return {"trials": trials, "recall": ok / trials, "against": "CPU restatement (oracle) on the same clouds",
-            "sizes": "600-point models, 3000-point scenes, ref_point_df 3",
-            "worst_rot_diff_deg": worst[0], "worst_trans_diff_frac_diam": worst[1]}
+    small = {"trials": trials, "recall": ok / trials, "sizes": "600-point models, 3000-point scenes, ref_point_df 3, oracle run live",
+             "worst_rot_diff_deg": worst[0], "worst_trans_diff_frac_diam": worst[1]}
+    if "trials" in out:
+        out["small_registrations"] = small
+    else:
+        out.update(small)
+    return out
 
 
 def cpu_baseline(mp, mn, sp, sn, df, d_dist):

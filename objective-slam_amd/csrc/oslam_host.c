@@ -352,6 +352,9 @@ void oslam_model_destroy(oslam_model *m)
     if (m->table.slots) (void)hipFree(m->table.slots);
     if (m->ent.e4) (void)hipFree(m->ent.e4);
     if (m->ent.uv) (void)hipFree(m->ent.uv);
+    if (m->ent.pw) (void)hipFree(m->ent.pw);
+    if (m->ent.puv) (void)hipFree(m->ent.puv);
+    if (m->ent.pdir) (void)hipFree(m->ent.pdir);
     if (m->ent.mi) (void)hipFree(m->ent.mi);
     if (m->table.ukeys && !m->shared_union) (void)hipFree(m->table.ukeys);
     if (m->table.reach && !m->shared_union) (void)hipFree(m->table.reach);
@@ -544,6 +547,17 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->ent.e4, (int)PC_ROW_SINK, n_pairs + 256, (hipStream_t)g_stream));
     KCHK(oslamk_model_fill(m->c.k, m->d_dist, m->inv_d_dist, m->table, d_tmg, m->ent, g_stream));
     if (!m->params.no_bucket_spread) KCHK(oslamk_bucket_spread(m->table, m->ent, g_stream));   /* the switch is for A/B measurements */
+    if (m->ent.uv) {
+        /* exact mode: every bucket once more in the order of the votes' positions inside their bins, with the uv of
+         * its entries (oslamk_entries.pw / .puv); the uv in bucket order are not needed after that */
+        HIPCHK(hipMalloc((void **)&m->ent.pw, sizeof(uint32_t) * n_pairs));
+        HIPCHK(hipMalloc((void **)&m->ent.puv, sizeof(oslamk_uv) * n_pairs));
+        HIPCHK(hipMalloc((void **)&m->ent.pdir, sizeof(uint16_t) * (n_pairs + 256)));
+        KCHK(oslamk_bucket_psort(m->table, m->ent, g_stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
+        (void)hipFree(m->ent.uv);
+        m->ent.uv = NULL;
+    }
     rc = build_uinfo(m);
     if (rc != OSLAM_OK) goto done;
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
@@ -568,8 +582,9 @@ done:
 static int build_uinfo(oslam_model *m);
 
 #define OSLAM_DB_MAGIC 0x4c444d4f534c4f00ull     /* "\0OLSOMDL" */
-#define OSLAM_DB_VERSION 6u                      /* table layout: 16-B slots, slices of 2046 points, e4 = theta (2^-21 turn) << 11 | half << 10 | row,
-                                                  * padding words = row 1023; checksum covers the header */
+#define OSLAM_DB_VERSION 7u                      /* table layout: 16-B slots, slices of 2046 points, e4 = theta (2^-21 turn) << 11 | half << 10 | row,
+                                                  * padding words = row 1023; checksum covers the header;
+                                                  * 7: exact mode stores the buckets a second time in vote-position order (pw, puv) instead of uv */
 typedef struct db_header {
     uint64_t magic;
     uint32_t version, vote_mode;
@@ -651,7 +666,7 @@ int oslam_model_save(const oslam_model *m, const char *path)
     hd.ucap = m->table.ucap;
     hd.ushift = m->table.ushift;
     hd.n_entries = m->n_entries;
-    hd.has_uv = m->ent.uv ? 1u : 0u;
+    hd.has_uv = m->ent.pw ? 1u : 0u;
     hd.num_model_keys = m->num_model_keys;
     hd.d_dist = m->d_dist;
     hd.inv_d_dist = m->inv_d_dist;
@@ -672,7 +687,9 @@ int oslam_model_save(const oslam_model *m, const char *path)
     if (rc == OSLAM_OK) rc = db_write_dev(f, m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), &sum);
     if (rc == OSLAM_OK) rc = db_write_dev(f, m->ent.e4, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK) rc = db_write_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
-    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.uv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.pw, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.puv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.pdir, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
     if (rc != OSLAM_OK) goto done;
     hd.checksum = sum;
     if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&hd, sizeof hd, 1, f) != 1) rc = fail(OSLAM_E_INVALID, "short write");
@@ -763,7 +780,11 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     HIPCHK(hipMalloc((void **)&m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32)));
     HIPCHK(hipMalloc((void **)&m->ent.e4, sizeof(uint32_t) * (n_pairs + 256)));   /* + a chunk: the vote kernel loads whole chunks */
     HIPCHK(hipMalloc((void **)&m->ent.mi, sizeof(uint16_t) * n_pairs));
-    if (hd.has_uv) HIPCHK(hipMalloc((void **)&m->ent.uv, sizeof(oslamk_uv) * n_pairs));
+    if (hd.has_uv) {
+        HIPCHK(hipMalloc((void **)&m->ent.pw, sizeof(uint32_t) * n_pairs));
+        HIPCHK(hipMalloc((void **)&m->ent.puv, sizeof(oslamk_uv) * n_pairs));
+        HIPCHK(hipMalloc((void **)&m->ent.pdir, sizeof(uint16_t) * (n_pairs + 256)));
+    }
     HIPCHK(hipMemcpy(m->table.slots, h_slots, sizeof(oslamk_slot) * n_slots, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->ent.e4, (int)PC_ROW_SINK, n_pairs + 256, (hipStream_t)g_stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
@@ -771,7 +792,9 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->table.reach, sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32), &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.e4, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
-    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.uv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.pw, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.puv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.pdir, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
     if (rc != OSLAM_OK) goto done;
     if (sum != hd.checksum) { rc = fail(OSLAM_E_INVALID, "model file checksum mismatch"); goto done; }
     m->h_slots = h_slots;                         /* the bucket tap reads it */
@@ -805,7 +828,7 @@ int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint
         *table_bytes = sizeof(oslamk_slot) * (uint64_t)m->table.cap * (uint64_t)m->table.n_slices +
                        sizeof(uint32_t) * (uint64_t)m->table.ucap + sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32) +
                        sizeof(oslamk_uinfo) * (uint64_t)m->table.uinfo_stride * (uint64_t)m->table.n_slices +
-                       (uint64_t)m->n_entries * (4 + 2 + (m->ent.uv ? 8 : 0)) + 24ull * (uint64_t)m->c.n;
+                       (uint64_t)m->n_entries * (4 + 2 + (m->ent.pw ? 14 : 0)) + 24ull * (uint64_t)m->c.n;
     return OSLAM_OK;
 }
 

@@ -41,9 +41,25 @@ typedef struct oslamk_uv {
 
 typedef struct oslamk_entries {
     uint32_t *e4;
-    oslamk_uv *uv;             /* NULL in fast mode */
+    oslamk_uv *uv;             /* build time only (bucket order of e4); NULL afterwards and in fast mode */
     uint16_t *mi;
+    /* exact mode: every bucket a second time, ordered by the position its entries' votes take inside a bin --
+     * P(word) = (word * 30) mod 2^32 -- in segments of OSLAMK_PSEG entries: pw = the words, puv = their uv.  A
+     * hit's votes that fall within the margin of a bin edge are the entries with (P(base) - P(word)) mod 2^32
+     * below PC_T24_EDGE: a contiguous piece of this order, found by a binary search per (hit, bucket) instead of
+     * a test per vote; only those (one vote in 4000) are re-evaluated with the reference's float sequence. */
+    uint32_t *pw;
+    oslamk_uv *puv;
+    /* directory of that order: a segment of n entries at bucket offset b is cut into K = oslamk_pdir_cells(n) cells of
+     * equal width in P (one or two entries each on average); pdir[b + k], k = 0 .. K, is the position inside the
+     * segment of the first entry whose cell is >= k (pdir[b + K] = n).  The search for a hit's near-edge entries is two
+     * 2-byte loads and the one or two cells between them, not a binary search. */
+    uint16_t *pdir;
 } oslamk_entries;
+#define OSLAMK_PSEG 4096       /* entries per sorted segment of a bucket (one LDS sort) */
+/* cells of a segment of n entries: the largest power of two below n (at least 1), so that K + 1 directory places fit the
+ * n places the segment owns in pdir (a bucket is padded to a multiple of 4 entries: a segment of one still has two) */
+#define OSLAMK_PDIR_CELLS(n) ((n) <= 1u ? 1u : 1u << (31 - __builtin_clz((n) - 1u)))
 
 /* A cloud in HBM: structure of arrays. */
 typedef struct oslamk_cloud {
@@ -135,6 +151,8 @@ int oslamk_model_fill(oslamk_cloud c, float d_dist, float inv_d_dist, oslamk_tab
 /* model build, pass 3: inside every bucket, order the entries so that the 32 lanes the LDS serves
  * together carry evenly spaced theta_u (fewer bank conflicts of the vote atomics) */
 int oslamk_bucket_spread(oslamk_table t, oslamk_entries ent, void *stream);
+/* model build, pass 4 (exact mode): ent.pw / ent.puv from ent.e4 / ent.uv, see oslamk_entries */
+int oslamk_bucket_psort(oslamk_table t, oslamk_entries ent, void *stream);
 
 /* A scene pair whose key is in the model ("hit"): what a vote needs of it.  The rows y,z of
  * T_s_g * s_i (kernel.cu:334-336) that the rare exact re-evaluation needs are recomputed from the

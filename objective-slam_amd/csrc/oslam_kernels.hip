@@ -377,6 +377,64 @@ __global__ __launch_bounds__(SPREAD_THREADS) void k_bucket_spread(oslamk_table t
     }
 }
 
+/* pass 4 (exact mode): every bucket once more, in segments of OSLAMK_PSEG entries ordered by P(word) = (word * 30)
+ * mod 2^32 -- the position inside its bin that the entry's vote takes, up to the hit's constant (oslamk_entries).
+ * ent.pw gets the words, ent.puv their uv (what a re-evaluation reads).  One workgroup per slot. */
+__global__ __launch_bounds__(SPREAD_THREADS) void k_bucket_psort(oslamk_table t, oslamk_entries ent)
+{
+    __shared__ unsigned long long key[OSLAMK_PSEG];    /* P << 32 | index in the segment */
+    __shared__ uint32_t s_e4[OSLAMK_PSEG];
+    __shared__ oslamk_uv s_uv[OSLAMK_PSEG];
+    const oslamk_slot sl = t.slots[blockIdx.x];
+    if (sl.key == 0 || sl.len == 0) return;
+    const int tid = threadIdx.x;
+    for (uint32_t seg = 0; seg < sl.len; seg += OSLAMK_PSEG) {
+        const uint32_t n = sl.len - seg < OSLAMK_PSEG ? sl.len - seg : OSLAMK_PSEG;
+        const size_t base = (size_t)sl.start + seg;
+        uint32_t P = 2;
+        while (P < n) P <<= 1;
+        for (uint32_t i = tid; i < P; i += SPREAD_THREADS) {
+            if (i < n) {
+                const uint32_t w = ent.e4[base + i];
+                s_e4[i] = w;
+                s_uv[i] = ent.uv[base + i];
+                key[i] = ((unsigned long long)(w * 30u) << 32) | i;
+            } else {
+                key[i] = ~0ull;
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t x = tid; x < P / 2; x += SPREAD_THREADS) {
+                    const uint32_t lo = ((x & ~(j - 1)) << 1) | (x & (j - 1)), hi = lo | j;
+                    const unsigned long long a = key[lo], b = key[hi];
+                    const bool up = (lo & k) == 0;
+                    if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < n; i += SPREAD_THREADS) {
+            const uint32_t src = (uint32_t)key[i];
+            ent.pw[base + i] = s_e4[src];
+            ent.puv[base + i] = s_uv[src];
+        }
+        /* the directory: first position whose cell (the top log2 K bits of P) is >= k */
+        const uint32_t K = OSLAMK_PDIR_CELLS(n);
+        for (uint32_t k = tid; k <= K; k += SPREAD_THREADS) {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t cell = (uint32_t)(((key[mid] >> 32) * (unsigned long long)K) >> 32);
+                if (cell < k) lo = mid + 1; else hi = mid;
+            }
+            ent.pdir[base + k] = (uint16_t)lo;
+        }
+        __syncthreads();
+    }
+}
+
 /* --------------------------------------------------------------------------
  * voting
  * ------------------------------------------------------------------------*/
@@ -437,11 +495,11 @@ __device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
  * the atomics (EXEC), padding entries vote into the accumulator's sink row. */
 #define ACC_TRASH_WORDS 96              /* slack behind the accumulator (16-byte zeroing, alignment of what follows) */
 
-/* what the re-evaluation of a vote reads besides the entry: the reference point's hit list, the
- * scene cloud and the rows y,z of T_s_g (kernel.cu:334-336) */
+/* what the re-evaluation of a vote reads: the model's entries in the order of oslamk_entries.pw / .puv, the
+ * reference point's hit list, the scene cloud and the rows y,z of T_s_g (kernel.cu:334-336) */
 struct SlowCtx {
-    const uint32_t *e4;
-    const oslamk_uv *uv;
+    const uint32_t *pw;
+    const oslamk_uv *puv;
     const oslamk_pay *hits;
     const float *px, *py, *pz;
     const float *rows;
@@ -472,11 +530,11 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) SlowCtx lds_ctx;
 
-/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index, hit index};
- * their operands are a dependent gather that would stall the stream, so they are evaluated 64 at
- * a time by slow_queue_flush().  q: the wave's SLOW_CAP places; n: how many are taken (wave-uniform). */
+/* Per-wave queue (LDS) of votes to re-evaluate with pc_alpha_bin_table: {entry index (pw order), hit index};
+ * their operands are a dependent gather, so they are evaluated 64 at a time by slow_queue_flush().
+ * q: the wave's SLOW_CAP places; n: how many are taken (wave-uniform). */
 #define SLOW_CAP 96
-#define SLOW_VERIFY 0x80000000u        /* in an item's entry index: the four votes entry .. entry+3 of the hit have been cast */
+#define SLOW_VERIFY 0x80000000u        /* in an item's entry index: the vote has been cast into its quantised bin */
 
 __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_u32 *tbl, lds_u64 *q, uint32_t n, int lane)
 {
@@ -490,36 +548,26 @@ __device__ __forceinline__ void slow_queue_flush(lds_ctx *sc, lds_u32 *acc, lds_
             const float x = sc->px[i], y = sc->py[i], z = sc->pz[i];
             const float vy = pc_row_dot(sc->rows, x, y, z);        /* as k_scene_hits computed them */
             const float vz = pc_row_dot(sc->rows + 4, x, y, z);
+            const uint32_t ew = sc->pw[entry];
+            const uint32_t mr = ew & PC_ROW10_MASK;
+            const uint32_t inc = (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo;
+            const float2 uv = *reinterpret_cast<const float2 *>(&sc->puv[entry]);
+            const unsigned bin = alpha_bin_reeval(uv.x, uv.y, vy, vz, t);
             if (!((uint32_t)it & SLOW_VERIFY)) {
                 /* a vote that has not been cast (an item with a marker) */
-                const uint32_t ew = sc->e4[entry];
-                const uint32_t mr = ew & PC_ROW10_MASK;
-                const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry]);
-                const unsigned bin = alpha_bin_reeval(uv.x, uv.y, vy, vz, t);
-                if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo);
+                if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], inc);
                 else atomicAdd((uint32_t *)&sc->dropped, 1u);
             } else {
-                /* four votes that have been cast, at least one of them within the margin of a bin edge: those are
-                 * evaluated with the reference's float sequence and moved if the quantised bin was not the
-                 * reference's (a counter word is only ever added to and subtracted from, so a carry between its two
-                 * halves that the misplaced vote caused is undone with it) */
-                const uint32_t csm = pc_vote_base_t32(hp.theta_t22);
-#pragma nounroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t ew = sc->e4[entry + j];
-                    const uint32_t mr = ew & PC_ROW10_MASK;
-                    uint32_t qbin, pos;
-                    vote_product(csm - ew, qbin, pos);
-                    if (mr != PC_ROW_SINK && pos < PC_T24_EDGE) {
-                        const float2 uv = *reinterpret_cast<const float2 *>(&sc->uv[entry + j]);
-                        const unsigned bin = alpha_bin_reeval(uv.x, uv.y, vy, vz, t);
-                        if (bin != qbin) {
-                            const uint32_t inc = (ew >> PC_ROW_HALF_BIT) & 1u ? sc->inc_hi : sc->inc_lo;
-                            atomicSub((uint32_t *)&acc[mr * ACC_STRIDE + qbin], inc);
-                            if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], inc);
-                            else atomicAdd((uint32_t *)&sc->dropped, 1u);
-                        }
-                    }
+                /* a vote that has been cast into its quantised bin and lies within the margin of a bin edge: moved if
+                 * the reference's float sequence puts it into another bin (a counter word is only ever added to and
+                 * subtracted from, so a carry between its two halves that a misplaced vote caused is undone with it,
+                 * whichever of the two comes first) */
+                uint32_t qbin, pos;
+                vote_product(pc_vote_base_t32(hp.theta_t22) - ew, qbin, pos);
+                if (bin != qbin) {
+                    atomicSub((uint32_t *)&acc[mr * ACC_STRIDE + qbin], inc);
+                    if (bin < OSLAMK_NBIN) atomicAdd((uint32_t *)&acc[mr * ACC_STRIDE + bin], inc);
+                    else atomicAdd((uint32_t *)&sc->dropped, 1u);
                 }
             }
         }
@@ -589,21 +637,16 @@ struct VoteRegs {
         th = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(&hits[d.h0].theta_t22) +
                                                  ((uint32_t)lane < d.R ? lane8 : 0u));
     }
-    /* returns the length of the wave's re-evaluation queue */
-    __device__ __forceinline__ uint32_t vote(const SlowCtx *scp, uint32_t *accp, const uint32_t *tblp, unsigned long long *qp,
-                                             uint32_t qn, const VoteStep &d, int lane, uint32_t inc_lo, uint32_t inc_hi) const
+    __device__ __forceinline__ void vote(uint32_t *accp, const VoteStep &d, int lane, uint32_t inc_lo, uint32_t inc_hi) const
     {
-        lds_ctx *sc = (lds_ctx *)scp;
-        lds_u32 *acc = (lds_u32 *)accp, *tbl = (lds_u32 *)tblp;
-        lds_u64 *q = (lds_u64 *)qp;
+        lds_u32 *acc = (lds_u32 *)accp;
         /* the entry words as they are: theta_u << 11 | half << 10 | row (pc_entry_word); lanes and words past the
          * end of the bucket are masked out of the atomics (EXEC) or are padding entries that vote into the sink
          * row.  A counter word holds two 16-bit counters: the model points of the lower half of the slice add 1,
          * those of the upper half 0x10000 (inc_lo / inc_hi; one of them is 0 in the rare second and third pass
          * of a workgroup whose 16-bit counters overflowed) */
         const uint32_t wa[4] = {v.x, v.y, v.z, v.w};
-        /* pc_vote_base_t32(th) = (th << 10) + a constant, which is kept in a scalar register (the compiler would
-         * park it in a vector register that exact mode does not have to spare) */
+        /* pc_vote_base_t32(th) = (th << 10) + a constant, which is kept in a scalar register */
         uint32_t csmv;
         asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(csmv) : "v"(th), "s"(pc_vote_base_t32(0u)));
         const uint32_t acc_base = (uint32_t)(uintptr_t)acc;  /* the accumulator's LDS address */
@@ -615,37 +658,27 @@ struct VoteRegs {
              * because the compiler turns every spelling of it into and + compare + select */
             if (inc_hi == 0x10000u)
                 asm("v_bfe_u32 %0, %1, 10, 1\n\tv_mad_u32_u24 %0, %0, %2, 1" : "=&v"(inc[j]) : "v"(wa[j]), "s"(0xffffu));
-            else
-                inc[j] = (wa[j] >> PC_ROW_HALF_BIT) & 1u ? inc_hi : inc_lo;
+            else                         /* the wide passes count one half of the slice's model points with 32-bit counters: 1 or 0 */
+                inc[j] = ((wa[j] >> PC_ROW_HALF_BIT) & 1u) ^ (inc_lo ? 1u : 0u);
         }
         /* lanes that hold at least one entry of this chunk */
         const unsigned long long live = __ballot((uint32_t)lane < (d.left + 3u) >> 2);
 #ifdef VOTE_DIAG_NOLOOP                 /* timing-only build: steps and loads without the votes */
         asm volatile("" ::"v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(csmv), "s"(live));
-        return qn;
+        return;
 #endif
+        /* Every vote goes into its quantised bin, in both modes: v_readlane + 4 x (v_sub, v_mad_u64_u32, v_lshl_add) =
+         * 13 vector instructions and 4 LDS atomics per hit and chunk.  In exact mode the votes that lie within the
+         * margin of a bin edge are found afterwards, by search (vote_body: correct_set), and moved where the
+         * reference's float sequence says so. */
         for (uint32_t i = d.i0; i < d.i1; i++) {
             const uint32_t csm = readlane_u(csmv, (int)i);
-            uint32_t addr[4], pos[4];
+            uint32_t addr[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t bin;
-                vote_product(csm - wa[j], bin, pos[j]);
+                uint32_t bin, pos;
+                vote_product(csm - wa[j], bin, pos);
                 addr[j] = rowb[j] + (bin << 2);
-            }
-            if (MODE == 0) {
-                /* position inside the (shifted) bin, in 2^-32 bin: below PC_T24_EDGE = within the margin of an
-                 * edge.  One compare of the smallest of the four finds the lanes that have such a vote; their
-                 * four votes are cast like all others and noted in the wave's queue, whose flush looks at them again
-                 * and moves the ones that the reference's float sequence puts into the other bin (one vote in 2000
-                 * is near an edge, one in eight of those moves).  Lanes past the bucket end cast nothing. */
-                const uint32_t lo3 = min(min(pos[0], pos[1]), pos[2]);
-                const unsigned long long near = __ballot(min(lo3, pos[3]) < PC_T24_EDGE) & live;
-                if (__builtin_expect(near != 0ull, 0)) {
-                    uint32_t e = 4u * (uint32_t)lane;
-                    asm volatile("" : "+v"(e));          /* keeps the item's arithmetic on the cold side of the branch */
-                    qn = slow_push(sc, acc, tbl, q, qn, near, (d.e0 + e) | SLOW_VERIFY, d.h0 + i, lane);
-                }
             }
 #ifdef VOTE_DIAG_NOATOM             /* timing-only build: the vote arithmetic without the LDS atomics */
             asm volatile("" ::"v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]));
@@ -664,7 +697,6 @@ struct VoteRegs {
                            "v"(inc[2]), "v"(inc[3])
                          : "memory");
         }
-        return qn;
     }
 };
 
@@ -909,6 +941,9 @@ __global__ __launch_bounds__(256) void k_scene_hits(oslamk_vote_args a)
  * Workgroups b and b + 8 share an XCD (speed only): the slices of one reference point are placed
  * on one XCD, so its hit and run lists reach one L2 once.
  * ------------------------------------------------------------------------*/
+#ifndef VOTE_DIAG_CORR
+#define VOTE_DIAG_CORR 0
+#endif
 #define VOTE_QCAP 1024
 #ifndef VOTE_BLOCK
 #define VOTE_BLOCK 16
@@ -953,8 +988,8 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
     const uint32_t *e4 = a.ent.e4;
     const uint32_t m_base = (uint32_t)slice * OSLAMK_SLICE;   /* first model reference of the slice */
     if (tid == 0) {
-        s_ctx.e4 = e4;
-        s_ctx.uv = a.ent.uv;
+        s_ctx.pw = a.ent.pw;
+        s_ctx.puv = a.ent.puv;
         s_ctx.hits = hits;
         s_ctx.px = a.scene.px;
         s_ctx.py = a.scene.py;
@@ -1107,7 +1142,79 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
                     }
                     asm volatile("" ::: "memory");      /* all the group's loads are issued here, in this order: none sinks into its vote */
     #pragma unroll
-                    for (int g = 0; g < VOTE_GROUP; g++) sq_n = regs[g].vote(sc, acc, s_tbl, sq, sq_n, ds[g], lane, inc_lo, inc_hi);
+                    for (int g = 0; g < VOTE_GROUP; g++) regs[g].vote(acc, ds[g], lane, inc_lo, inc_hi);
+                }
+            }
+        };
+        /* Exact mode, after the votes of a set of items: the votes that lie within the margin of a bin edge, found
+         * instead of tested for.  A vote of hit h with entry word w has position (P(base_h) - P(w)) mod 2^32 inside
+         * its (shifted) bin, P(x) = x * 30 mod 2^32 -- the low word of vote_product -- and is near an edge when that
+         * is below PC_T24_EDGE.  The bucket exists a second time ordered by P(w) (oslamk_entries.pw, segments of
+         * OSLAMK_PSEG entries), so the near-edge entries of a hit are a contiguous piece of it, cyclically: from the
+         * first entry with P(w) >= A = P(base_h) - PC_T24_EDGE + 1 on, as long as (P(w) - A) mod 2^32 < PC_T24_EDGE.
+         * One lane per (hit, bucket segment) pair of the set: a binary search, then the candidates -- one vote in
+         * 4000 -- go to the wave's queue, whose flush moves those that the reference's float sequence bins otherwise.
+         * u0 / stride: which of the set's pairs this wave takes (giants are shared out between the waves). */
+        auto correct_set = [&](bool take, uint32_t u0, uint32_t stride) {
+            const uint32_t *pw = a.ent.pw;
+            const uint16_t *pdir = a.ent.pdir;
+            uint32_t excl, incl;
+            {
+                const uint32_t R = (B_ru.x >> OSLAMK_RUN_SHIFT) + 1u, ln = B_inf.y & 0x7fffffffu;
+                const uint32_t np = take ? R * ((ln + OSLAMK_PSEG - 1u) / OSLAMK_PSEG) : 0u;
+                incl = np;
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o, WAVE);
+                    if (lane >= o) incl += up;
+                }
+                excl = incl - np;
+            }
+            const uint32_t total = readlane_u(incl, WAVE - 1);
+            for (uint32_t pb = u0; pb < total; pb += stride * WAVE) {
+                const uint32_t p = pb + stride * (uint32_t)lane;
+                const bool act = p < total;
+                uint32_t lo = 0;                                   /* items whose running sum is <= p: the pair's item */
+    #pragma unroll
+                for (uint32_t s2 = WAVE / 2; s2 > 0; s2 >>= 1) lo += bperm(lo + s2 - 1u, incl) <= p ? s2 : 0u;
+                lo = lo < (uint32_t)WAVE - 1u ? lo : (uint32_t)WAVE - 1u;
+                const uint32_t st = bperm(lo, B_inf.x), ln = bperm(lo, B_inf.y) & 0x7fffffffu, h0 = bperm(lo, B_ru.y) & 0x7fffffffu;
+                const uint32_t R = (bperm(lo, B_ru.x) >> OSLAMK_RUN_SHIFT) + 1u;
+                uint32_t local = p - bperm(lo, excl), seg = 0;
+                if (__ballot(act && local >= R)) {               /* buckets above OSLAMK_PSEG entries: rare */
+                    seg = act ? local / R : 0u;
+                    local -= seg * R;
+                }
+                const uint32_t hit = act ? h0 + local : 0u;
+                const uint32_t sbase = act ? st + seg * OSLAMK_PSEG : 0u;
+                const uint32_t n = act ? (ln - seg * OSLAMK_PSEG < OSLAMK_PSEG ? ln - seg * OSLAMK_PSEG : OSLAMK_PSEG) : 0u;
+#if VOTE_DIAG_CORR == 1                /* timing-only build: the enumeration of the pairs alone */
+                asm volatile("" ::"v"(hit), "v"(sbase), "v"(n));
+                continue;
+#endif
+                const uint32_t A = pc_vote_base_t32(hits[hit].theta_t22) * 30u - (PC_T24_EDGE - 1u);
+                /* the cells the window [A, A + PC_T24_EDGE) touches, through the segment's directory: positions
+                 * d0 .. d0 + cnt - 1 (cyclic) hold every near-edge entry, and a few that are not */
+                const uint32_t K = OSLAMK_PDIR_CELLS(n), B = A + (PC_T24_EDGE - 1u);
+                const uint32_t cA = __umulhi(A, K), cB = __umulhi(B, K);
+                const uint32_t d0 = act ? pdir[sbase + cA] : 0u, d1 = act ? pdir[sbase + cB + 1u] : 0u;
+                const uint32_t cnt = K == 1u ? n : B < A ? n - d0 + d1 : d1 - d0;       /* B < A: the window wraps past 2^32 */
+#if VOTE_DIAG_CORR == 2                /* timing-only build: up to the directory, without the entries */
+                asm volatile("" ::"v"(cnt), "v"(d0));
+                continue;
+#endif
+                for (uint32_t c0 = 0; __ballot(c0 < cnt); c0 += 4u) {
+                    uint32_t k[4], w[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        k[j] = d0 + c0 + (uint32_t)j;
+                        k[j] = k[j] >= n ? k[j] - n : k[j];
+                        w[j] = pw[sbase + (c0 + (uint32_t)j < cnt ? k[j] : 0u)];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const unsigned long long nm = __ballot(c0 + (uint32_t)j < cnt && w[j] * 30u - A < PC_T24_EDGE);
+                        if (nm) sq_n = slow_push((lds_ctx *)sc, (lds_u32 *)acc, (lds_u32 *)s_tbl, (lds_u64 *)sq, sq_n, nm, (sbase + k[j]) | SLOW_VERIFY, hit, lane);
+                    }
                 }
             }
         };
@@ -1194,6 +1301,9 @@ __device__ __forceinline__ void vote_body(const oslamk_vote_args &a, const uint3
                     turn++;
                 }
                 vote_set(take, split, u0, stride);
+#ifndef VOTE_DIAG_NOCORRECT          /* timing-only build: exact mode without the near-edge search */
+                if (MODE == 0) correct_set(take, u0, stride);
+#endif
             }
         }
         if (MODE == 0) {
@@ -1381,10 +1491,14 @@ template <int MODE, int PASS>
 __global__ __launch_bounds__(VOTE_THREADS) void k_vote_wide(oslamk_vote_args a)
 {
     const uint32_t n = a.counters->redo_count;
+#ifdef WIDE_NOLOOP_EXPERIMENT
+    if (blockIdx.x < n) vote_body<MODE, PASS>(a, a.redo[blockIdx.x]);
+#else
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         vote_body<MODE, PASS>(a, a.redo[i]);
         __syncthreads();                            /* the LDS of this workgroup is reused by the next entry */
     }
+#endif
 }
 
 /* --------------------------------------------------------------------------
@@ -1531,6 +1645,13 @@ int oslamk_bucket_spread(oslamk_table t, oslamk_entries ent, void *stream)
 {
     const size_t total = (size_t)t.n_slices * t.cap;
     hipLaunchKernelGGL(k_bucket_spread, dim3((unsigned)total), dim3(SPREAD_THREADS), 0, (hipStream_t)stream, t, ent);
+    return (int)hipGetLastError();
+}
+
+int oslamk_bucket_psort(oslamk_table t, oslamk_entries ent, void *stream)
+{
+    const size_t total = (size_t)t.n_slices * t.cap;
+    hipLaunchKernelGGL(k_bucket_psort, dim3((unsigned)total), dim3(SPREAD_THREADS), 0, (hipStream_t)stream, t, ent);
     return (int)hipGetLastError();
 }
 

@@ -218,15 +218,16 @@ static int hash_idx_order(const void *a, const void *b)
     if (x->hash != y->hash) return x->hash < y->hash ? -1 : 1;
     return x->idx < y->idx ? -1 : (x->idx > y->idx);
 }
-/* first position whose hash is >= h */
-static size_t hash_lower_bound(const hash_idx *v, size_t n, uint32_t h)
+/* do-across loops: wait until *flag is set by the thread that owns a lower index.  Spins briefly, then yields: the
+ * host may have fewer free cores than threads */
+#include <sched.h>
+static inline unsigned char wait_flag(const unsigned char *flag)
 {
-    size_t lo = 0, hi = n;
-    while (lo < hi) {
-        size_t mid = lo + (hi - lo) / 2;
-        if (v[mid].hash < h) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+    unsigned char v;
+    unsigned spins = 0;
+    while (!(v = __atomic_load_n(flag, __ATOMIC_ACQUIRE)))
+        if (++spins > 200) { sched_yield(); spins = 0; }
+    return v;
 }
 
 static __thread oslam_cluster_hook g_cluster_hook;
@@ -260,53 +261,94 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
     qsort(hi, n, sizeof(hash_idx), hash_idx_order);
 
     /* Each pose scans its 26 neighbour cells in a fixed order, so its float sums do not depend
-     * on the other poses -- unless translations are averaged in place (kernel.cu:747-758), which
-     * stays serial in index order.  Large sets go to the GPU (k_cluster_scores: same sums, same
-     * order), otherwise host threads: at most 16 (a 1-GPU share of the host). */
+     * on the other poses -- unless translations are averaged in place (kernel.cu:747-758): then pose i
+     * sees the updated translation of every pose o < i and the original one of every o > i (the update is
+     * applied in index order where the reference races).  Large sets of the plain variant go to the GPU
+     * (k_cluster_scores: same sums, same order); otherwise host threads, at most 16 (a 1-GPU share of the
+     * host).  The averaged variant runs on the same threads as a do-across loop: poses are handed out in
+     * index order, and a pose waits for a neighbour o < i only when it meets one (the lowest unfinished
+     * index never waits, so the loop cannot lock up); the reads of o > i go to a copy of the original
+     * translations.  The start of a cell's poses in the sorted list comes from a table, not a search. */
     if (!averaged && n >= 2048 && g_cluster_hook &&
         g_cluster_hook(n, trans, quat, wv, cell, (const uint32_t *)hi, d_dist, use_l1, score) == 0) {
         /* scores are in place */
     } else {
-        long ii;
         int threads = 1;
+        size_t cap = 64, next = 0;
+        uint32_t *rkey, *rpos;
+        float *orig = NULL;
+        unsigned char *done = NULL;
 #ifdef _OPENMP
         threads = g_host_threads ? g_host_threads : (omp_get_max_threads() < 16 ? omp_get_max_threads() : 16);
-        if (averaged || n < 512) threads = 1;
+        if (n < 512) threads = 1;
 #endif
-#pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
-        for (ii = 0; ii < (long)n; ii++) {
-            const size_t i = (size_t)ii;
-            const float *q = quat + 4 * i;
-            float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
-            float ox = tx, oy = ty, oz = tz;
-            float votes = 1;                                     /* kernel.cu:722 */
+        while (cap < 2 * n) cap <<= 1;
+        rkey = (uint32_t *)calloc(cap, sizeof(uint32_t));              /* cell hash -> first position in hi[]; 0 = empty */
+        rpos = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+        if (averaged) {
+            orig = (float *)malloc(sizeof(float) * 3 * n);
+            done = (unsigned char *)calloc(n, 1);
+        }
+        if (!rkey || !rpos || (averaged && (!orig || !done))) {
+            free(rkey); free(rpos); free(orig); free(done);
+            free(wv); free(score); free(cell); free(hi);
+            return NO_MEMORY;
+        }
+        if (averaged) memcpy(orig, trans, sizeof(float) * 3 * n);
+        for (i = 0; i < n; i++)
+            if (hi[i].hash != 0 && (i == 0 || hi[i].hash != hi[i - 1].hash)) {   /* a hash of 0 is never searched (kernel.cu:727) */
+                size_t sl = (hi[i].hash * 2654435761u) & (cap - 1);
+                while (rkey[sl]) sl = (sl + 1) & (cap - 1);
+                rkey[sl] = hi[i].hash;
+                rpos[sl] = (uint32_t)i;
+            }
+#pragma omp parallel num_threads(threads)
+        for (;;) {
+            size_t i;
+            const float *q;
+            float tx, ty, tz, ox, oy, oz, votes = 1;             /* kernel.cu:722 */
             int dx, dy, dz;
+            i = __atomic_fetch_add(&next, 1, __ATOMIC_RELAXED);
+            if (i >= n) break;
+            q = quat + 4 * i;
+            tx = averaged ? orig[3 * i] : trans[3 * i];
+            ty = averaged ? orig[3 * i + 1] : trans[3 * i + 1];
+            tz = averaged ? orig[3 * i + 2] : trans[3 * i + 2];
+            ox = tx; oy = ty; oz = tz;
             for (dx = -1; dx < 2; dx++)
                 for (dy = -1; dy < 2; dy++)
                     for (dz = -1; dz < 2; dz++) {
                         int32_t nb[3];
                         uint32_t h;
-                        size_t j;
+                        size_t j, sl;
                         if (dx == 0 && dy == 0 && dz == 0) continue;   /* kernel.cu:684-689 */
                         nb[0] = cell[3 * i] + dx; nb[1] = cell[3 * i + 1] + dy; nb[2] = cell[3 * i + 2] + dz;
                         h = fnv_cell(nb);
                         if (h == 0) continue;                          /* kernel.cu:727 */
-                        for (j = hash_lower_bound(hi, n, h); j < n && hi[j].hash == h; j++) {
+                        sl = (h * 2654435761u) & (cap - 1);
+                        while (rkey[sl] && rkey[sl] != h) sl = (sl + 1) & (cap - 1);
+                        if (!rkey[sl]) continue;
+                        for (j = rpos[sl]; j < n && hi[j].hash == h; j++) {
                             size_t o = hi[j].idx;
-                            const float *qo = quat + 4 * o;
+                            const float *qo = quat + 4 * o, *to;
                             float oc = wv[o];
                             float qd = fabsf(8 * (1 - (q[0] * qo[0] + q[1] * qo[1] + q[2] * qo[2] + q[3] * qo[3])));
                             if (!(qd < rot_thresh_sq)) continue;
+                            to = trans + 3 * o;
+                            if (averaged) {
+                                if (o < i) (void)wait_flag(&done[o]);              /* its update comes first */
+                                else to = orig + 3 * o;
+                            }
                             if (!use_l1) {
-                                float ex = tx - trans[3 * o], ey = ty - trans[3 * o + 1], ez = tz - trans[3 * o + 2];
+                                float ex = tx - to[0], ey = ty - to[1], ez = tz - to[2];
                                 if (!(sqrtf(ex * ex + ey * ey + ez * ez) < d_dist)) continue;
                             }
                             if (averaged) {                            /* kernel.cu:747-752 */
                                 float s;
                                 ox = votes * ox; oy = votes * oy; oz = votes * oz;
-                                ox = ox + wv[o] * trans[3 * o];
-                                oy = oy + wv[o] * trans[3 * o + 1];
-                                oz = oz + wv[o] * trans[3 * o + 2];
+                                ox = ox + wv[o] * to[0];
+                                oy = oy + wv[o] * to[1];
+                                oz = oz + wv[o] * to[2];
                                 s = 1 / (votes + oc);
                                 ox = s * ox; oy = s * oy; oz = s * oz;
                             }
@@ -314,8 +356,12 @@ static size_t cluster_by_cells(const oslam_cell *cells, size_t n, float *trans, 
                         }
                     }
             score[i] = votes;
-            if (averaged) { trans[3 * i] = ox; trans[3 * i + 1] = oy; trans[3 * i + 2] = oz; }   /* kernel.cu:758 */
+            if (averaged) {                                            /* kernel.cu:758 */
+                trans[3 * i] = ox; trans[3 * i + 1] = oy; trans[3 * i + 2] = oz;
+                __atomic_store_n(&done[i], 1, __ATOMIC_RELEASE);
+            }
         }
+        free(rkey); free(rpos); free(orig); free(done);
     }
     for (i = 1; i < n; i++) if (score[i] > score[best]) best = i;         /* model.cu:292-295 */
     if (score_out) memcpy(score_out, score, sizeof(float) * n);           /* vote_counts_out, model.h:104 */
@@ -373,33 +419,102 @@ int oslam_ht_dist(const float A[16], const float B[16], float out[2])
     return OSLAM_OK;
 }
 
-/* greedy clustering, transformation_clustering.cpp:62-122; poses arrive sorted
- * by votes; the first cluster's average pose is the result (ppf.cu:75-77) */
+/* greedy clustering, transformation_clustering.cpp:62-122; poses arrive sorted by votes; the first
+ * cluster's average pose is the result (ppf.cu:75-77).
+ *
+ * The reference walks the clusters in creation order for every pose (O(poses x clusters)) and joins the
+ * first whose head is within (trans_thresh, rot_thresh).  The same result here from a grid: a cluster
+ * head IS a pose, a head within trans_thresh of pose p lies in one of the 27 grid cells around p (cell
+ * edge a hair above trans_thresh), and "the first matching cluster" is the matching head of lowest index.
+ * So pose p looks at the poses q < p of those cells, waits until each is known to be a head or a member,
+ * tests the heads, and joins the lowest that matches -- or becomes a head.  Poses are handed out to the
+ * host threads in index order (a do-across loop: the lowest undecided pose never waits, so it cannot lock
+ * up); the votes of the clusters, the winner (first maximum in creation order) and its average are
+ * serial passes in the reference's order of summation. */
+typedef struct { int32_t c[3]; int32_t first; } grid_slot;
+
+static size_t grid_find(const grid_slot *g, size_t cap, const int32_t c[3])
+{
+    size_t sl = ((uint32_t)c[0] * 73856093u ^ (uint32_t)c[1] * 19349663u ^ (uint32_t)c[2] * 83492791u) & (cap - 1);
+    while (g[sl].first != -1 && (g[sl].c[0] != c[0] || g[sl].c[1] != c[1] || g[sl].c[2] != c[2])) sl = (sl + 1) & (cap - 1);
+    return sl;
+}
+
 static int cluster_greedy(const float *T, const oslam_cell *cells, size_t n, float trans_thresh,
                           float rot_thresh, float *T_out, uint32_t *votes_out)
 {
-    size_t *head = (size_t *)malloc(sizeof(size_t) * n);
-    size_t *member = (size_t *)malloc(sizeof(size_t) * n);
-    uint32_t *cvotes = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    size_t ncl = 0, p, c, win = 0, cnt = 0;
+    size_t *member = (size_t *)malloc(sizeof(size_t) * n);          /* the head (a pose index) of every pose's cluster */
+    uint32_t *cvotes = (uint32_t *)calloc(n, sizeof(uint32_t));       /* votes of the cluster whose head is pose p */
+    int32_t *pc = (int32_t *)malloc(sizeof(int32_t) * 3 * n), *nxt = (int32_t *)malloc(sizeof(int32_t) * n);
+    unsigned char *state = (unsigned char *)calloc(n, 1);             /* 0 undecided, 1 head, 2 member */
+    grid_slot *grid;
+    size_t cap = 64, p, win = 0, cnt = 0, next = 0;
+    const double inv = trans_thresh > 0 ? 1.0 / ((double)trans_thresh * 1.0001) : 0.0;
     float ta[3] = {0, 0, 0}, qa[4] = {0, 0, 0, 0}, nq, x, y, z, w;
-    int i, j;
-    if (!head || !member || !cvotes) {
-        free(head); free(member); free(cvotes);
+    int i, j, threads = 1;
+#ifdef _OPENMP
+    if (n >= 2048) threads = g_host_threads ? g_host_threads : (omp_get_max_threads() < 16 ? omp_get_max_threads() : 16);
+#endif
+    while (cap < 2 * n) cap <<= 1;
+    grid = (grid_slot *)malloc(sizeof(grid_slot) * cap);
+    if (!member || !cvotes || !pc || !nxt || !state || !grid || n > 0x7fffffffu) {
+        free(member); free(cvotes); free(pc); free(nxt); free(state); free(grid);
         return OSLAM_E_NOMEM;
     }
-    for (p = 0; p < n; p++) {
+    for (p = 0; p < cap; p++) grid[p].first = -1;
+    /* poses into the grid, highest index first, so that every cell's list ascends */
+    for (p = n; p-- > 0;) {
         const float *P = T + 16 * p;
-        for (c = 0; c < ncl; c++) {
-            const float *H = T + 16 * head[c];
-            float ex = P[3] - H[3], ey = P[7] - H[7], ez = P[11] - H[11];
-            if (sqrtf(ex * ex + ey * ey + ez * ez) < trans_thresh && relative_angle(P, H) < rot_thresh) break;
+        size_t sl;
+        int a;
+        for (a = 0; a < 3; a++) {
+            const double v = (double)P[4 * a + 3] * inv;
+            /* a translation that is not finite, or astronomically far out, matches nobody (the norm test fails):
+             * any cell will do */
+            pc[3 * p + a] = (v > -1e9 && v < 1e9) ? (int32_t)floor(v) : 0;
         }
-        if (c == ncl) { head[ncl] = p; cvotes[ncl] = 0; ncl++; }
-        member[p] = c;
-        cvotes[c] += cells[p].count;
+        sl = grid_find(grid, cap, pc + 3 * p);
+        if (grid[sl].first == -1) memcpy(grid[sl].c, pc + 3 * p, sizeof grid[sl].c);
+        nxt[p] = grid[sl].first == -1 ? -2 : grid[sl].first;          /* -2 ends a list (-1 marks an empty slot) */
+        grid[sl].first = (int32_t)p;
     }
-    for (c = 1; c < ncl; c++) if (cvotes[c] > cvotes[win]) win = c;   /* first of the sorted clusters */
+#pragma omp parallel num_threads(threads)
+    for (;;) {
+        const size_t pp = __atomic_fetch_add(&next, 1, __ATOMIC_RELAXED);
+        const float *P;
+        size_t best;
+        int dx, dy, dz;
+        if (pp >= n) break;
+        P = T + 16 * pp;
+        best = pp;
+        for (dx = -1; dx < 2; dx++)
+            for (dy = -1; dy < 2; dy++)
+                for (dz = -1; dz < 2; dz++) {
+                    int32_t c[3], q;
+                    size_t sl;
+                    c[0] = pc[3 * pp] + dx; c[1] = pc[3 * pp + 1] + dy; c[2] = pc[3 * pp + 2] + dz;
+                    sl = grid_find(grid, cap, c);
+                    for (q = grid[sl].first; q >= 0 && (size_t)q < pp; q = nxt[q]) {
+                        unsigned char st;
+                        const float *H;
+                        float ex, ey, ez;
+                        if ((size_t)q > best) break;                   /* the list ascends: nothing lower than the best so far is left in it */
+                        st = wait_flag(&state[q]);
+                        if (st != 1) continue;                         /* only heads are compared with (transformation_clustering.cpp:78-86) */
+                        H = T + 16 * (size_t)q;
+                        ex = P[3] - H[3]; ey = P[7] - H[7]; ez = P[11] - H[11];
+                        if (sqrtf(ex * ex + ey * ey + ez * ez) < trans_thresh && relative_angle(P, H) < rot_thresh && (size_t)q < best)
+                            best = (size_t)q;
+                    }
+                }
+        member[pp] = best;
+        __atomic_store_n(&state[pp], best == pp ? 1 : 2, __ATOMIC_RELEASE);
+    }
+    for (p = 0; p < n; p++) cvotes[member[p]] += cells[p].count;
+    for (p = 0; p < n; p++)                                            /* first of the sorted clusters: creation order = head index */
+        if (state[p] == 1) { win = p; break; }
+    for (p = win + 1; p < n; p++)
+        if (state[p] == 1 && cvotes[p] > cvotes[win]) win = p;
     for (p = 0; p < n; p++) {
         float R[9], q[4];
         if (member[p] != win) continue;
@@ -424,7 +539,7 @@ static int cluster_greedy(const float *T, const oslam_cell *cells, size_t n, flo
         T_out[12] = 0; T_out[13] = 0; T_out[14] = 0; T_out[15] = 1;
     }
     if (votes_out) *votes_out = cvotes[win];
-    free(head); free(member); free(cvotes);
+    free(member); free(cvotes); free(pc); free(nxt); free(state); free(grid);
     return OSLAM_OK;
 }
 

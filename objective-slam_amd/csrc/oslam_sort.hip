@@ -2,149 +2,182 @@
  * oslam_sort.hip -- the hit sort of the PPF registration path (gfx950): per scene reference point, the hits
  * ordered by key number and the list of runs of equal keys that the vote kernel works from.
  *
- * A translation unit of its own because it is built with -mllvm -disable-machine-licm: with the pass on, the
- * compiler hoists enough loop invariants of rocPRIM's sort over its passes to run the kernel, which has 16 keys and
- * 16 values per thread in registers, 4 registers over its 128 (20 bytes of scratch per lane); without it the
- * kernel fits (profiles/r02_kernel_resources.txt) at the same speed.
+ * The reference sorts its N^2 keys with thrust::sort_by_key (include/impl/parallel_hash_array.hpp:55-92) and looks
+ * every scene pair up with thrust::lower_bound (model.cu:96-97).  Here a reference point has a few thousand hits,
+ * each carrying the NUMBER of its key (16 bits for the 38 000 keys of a 5 k-point model, not the key's 32), and one
+ * workgroup orders them in LDS with a hand-written stable counting sort on 8-bit digits, least significant first:
+ *   per pass  1. every wave counts the digits of its contiguous share of the list (LDS atomics, 16 x 256 counters);
+ *             2. the counters become write positions: digit-major, wave-minor prefix sums;
+ *             3. every wave moves its share in order, 64 elements at a time: the lanes that hold the same digit
+ *                find each other with eight ballots, take consecutive places from the digit's position and advance it.
+ * An element is key number << 14 | position in the list (one 32-bit word: two buffers of 16 384 elements fit the LDS);
+ * key numbers above 18 bits (databases of many models in one group) take 64-bit elements and half the segment.  The
+ * run heads (a key changes, or 64 hits are full) come from the sorted words, the payloads are gathered into the second
+ * list.  A list longer than a segment is sorted in segments (a key then has one run per segment it occurs in: its
+ * bucket is streamed once per segment instead of once, everything else is unchanged).
  */
 #include <hip/hip_runtime.h>
-
-#include <cstring>   /* rocPRIM calls memset without including it */
-
-#include <rocprim/block/block_radix_sort.hpp>
 
 #include "oslam_kernels.h"
 #include "ppf_core.h"
 
 #define WAVE 64
-
-/* Orders the hit list of each reference point of the batch by key (by the key's slot in the union
- * table: log2(ucap) bits instead of 32), so that hits that share a bucket are adjacent (on the bench
- * scene a bucket is hit 3.8 times per reference point on average; streaming it once per run cuts
- * the entry traffic 4.7x), and writes the run list the vote kernel works from:
- * runs[u] = {slot | (hits - 1) << 26, index of the run's first hit | marker << 31}; a run also ends
- * at every multiple of 64 hits, so a run is at most one hit per lane.
- * One workgroup per reference point: radix sort of (slot, index) in LDS -- rocPRIM's block
- * primitive (DESIGN.md 4 says why it stays) -- then the payloads are gathered into the second list.
- * A list longer than SORT_MAX is sorted in segments of SORT_MAX hits (a key then has one run per
- * segment it occurs in: its bucket is streamed once per segment instead of once, everything else
- * is unchanged). */
-#define SORT_MAX 16384
 #define SORT_THREADS 1024
-#define SORT_ITEMS (SORT_MAX / SORT_THREADS)
-#define SORT_SMALL_ITEMS 2                      /* lists of up to 2048 hits (small scenes) take a 2-per-thread sort */
-typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_ITEMS, uint32_t> hit_block_sort;
-typedef rocprim::block_radix_sort<uint32_t, SORT_THREADS, SORT_SMALL_ITEMS, uint32_t> hit_block_sort_small;
+#define SORT_WAVES (SORT_THREADS / WAVE)
+#define SORT_IDX_BITS 14
+#define SORT_SEG32 (1 << SORT_IDX_BITS)          /* hits per segment with 32-bit elements */
+#define SORT_SEG64 (SORT_SEG32 / 2)              /* ... with 64-bit elements (key numbers above 18 bits) */
+#define SORT_RADIX 256
 
-/* One segment of n <= ITEMS * 1024 hits: sort, gather, run heads.  Returns the segment's run count (the
- * same value in every thread). */
-template <int ITEMS, class SORT>
-__device__ __forceinline__ uint32_t sort_segment(typename SORT::storage_type &s_sort, uint32_t *s_part, uint32_t *s_last,
-                                                 const uint32_t *skey, const oslamk_pay *spay, oslamk_pay *dst,
-                                                 oslamk_run *runs, uint32_t n, uint32_t seg, uint32_t n_runs,
-                                                 unsigned bits, int tid, int lane, int wid)
+__device__ __forceinline__ uint32_t sort_key_of(uint32_t e) { return e >> SORT_IDX_BITS; }
+__device__ __forceinline__ uint32_t sort_idx_of(uint32_t e) { return e & (SORT_SEG32 - 1u); }
+__device__ __forceinline__ uint32_t sort_pack(uint32_t key, uint32_t idx, uint32_t) { return (key << SORT_IDX_BITS) | idx; }
+__device__ __forceinline__ uint32_t sort_key_of(unsigned long long e) { return (uint32_t)(e >> 32); }
+__device__ __forceinline__ uint32_t sort_idx_of(unsigned long long e) { return (uint32_t)e; }
+__device__ __forceinline__ unsigned long long sort_pack(uint32_t key, uint32_t idx, unsigned long long)
 {
-    /* Thread t brings the hits ITEMS*t .. ITEMS*t+ITEMS-1 and ends up with the same sorted positions in
-     * registers.  Places past the end carry all ones; the sort is stable and they come last in the
-     * input order, so they also come last among equal keys and the first n sorted positions are the
-     * hits. */
-    const uint32_t i0 = (uint32_t)tid * ITEMS;
-    uint32_t key[ITEMS], idx[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const uint32_t i = i0 + k;
-        key[k] = i < n ? skey[i] : 0xffffffffu;
-        idx[k] = i;
-    }
-    SORT().sort(key, idx, s_sort, 0u, bits);
-    uint32_t marked = 0;                 /* sorted positions of this thread whose hit carries the marker */
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++)
-        if (i0 + k < n) {
-            const oslamk_pay py = spay[idx[k]];
-            dst[i0 + k] = py;
-            marked |= (uint32_t)(py.theta_t22 == PC_T22_FORCE) << k;
+    return ((unsigned long long)key << 32) | idx;
+}
+
+/* One segment of n <= SEG hits: sort, gather, run heads.  bufA / bufB: SEG elements each; s_hist [SORT_WAVES][256];
+ * s_part [SORT_WAVES + 1].  Returns the segment's run count (the same value in every thread). */
+template <typename E, int SEG>
+__device__ __forceinline__ uint32_t sort_segment(E *bufA, E *bufB, uint32_t *s_hist, uint32_t *s_part, const uint32_t *skey,
+                                                 const oslamk_pay *spay, oslamk_pay *dst, oslamk_run *runs, uint32_t n,
+                                                 uint32_t seg, uint32_t n_runs, unsigned bits, int tid, int lane, int wid)
+{
+    for (uint32_t i = (uint32_t)tid; i < n; i += SORT_THREADS) bufA[i] = sort_pack(skey[i], i, E());
+    /* the share of wave w: chunk hits, a multiple of 64, in list order */
+    const uint32_t chunk = ((n + SORT_WAVES * WAVE - 1u) / (SORT_WAVES * WAVE)) * WAVE;
+    const uint32_t c_lo = (uint32_t)wid * chunk < n ? (uint32_t)wid * chunk : n;
+    const uint32_t c_hi = c_lo + chunk < n ? c_lo + chunk : n;
+    uint32_t *hist = s_hist + wid * SORT_RADIX;
+    E *src = bufA, *out = bufB;
+    for (unsigned shift = 0; shift < bits; shift += 8) {
+        for (int k = tid; k < SORT_WAVES * SORT_RADIX; k += SORT_THREADS) s_hist[k] = 0;
+        __syncthreads();                /* also: the elements of the previous pass (or the load) are in src */
+        for (uint32_t i = c_lo + (uint32_t)lane; i < c_hi; i += WAVE) atomicAdd(&hist[(sort_key_of(src[i]) >> shift) & 255u], 1u);
+        __syncthreads();
+        /* counters -> positions: everything with a smaller digit first, then the lower waves' share of the same digit */
+        uint32_t tot = 0;
+        if (tid < SORT_RADIX) {
+            for (int w = 0; w < SORT_WAVES; w++) {
+                const uint32_t v = s_hist[w * SORT_RADIX + tid];
+                s_hist[w * SORT_RADIX + tid] = tot;
+                tot += v;
+            }
         }
-    s_last[tid] = key[ITEMS - 1];
-    __syncthreads();
-    uint32_t heads = 0, cnt = 0;
-    uint32_t prev = tid ? s_last[tid - 1] : 0u;
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const uint32_t i = i0 + k;
-        if (i < n) {
-            const bool head = (i & (WAVE - 1)) == 0 || key[k] != prev;
-            heads |= (uint32_t)head << k;
-            cnt += head;
+        uint32_t incl = tot;            /* inclusive scan of the digit totals over the first four waves */
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
         }
-        prev = key[k];
+        if (tid < SORT_RADIX && lane == WAVE - 1) s_part[wid] = incl;
+        __syncthreads();
+        if (tid < SORT_RADIX) {
+            uint32_t base = incl - tot;
+            for (int w = 0; w < wid; w++) base += s_part[w];
+            for (int w = 0; w < SORT_WAVES; w++) s_hist[w * SORT_RADIX + tid] += base;
+        }
+        __syncthreads();
+        /* the move, in order */
+        for (uint32_t i0 = c_lo; i0 < c_hi; i0 += WAVE) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool in = i < c_hi;
+            const E e = src[in ? i : c_lo];
+            const uint32_t digit = (sort_key_of(e) >> shift) & 255u;
+            unsigned long long same = __ballot(in);            /* the lanes that hold the same digit as this one */
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long bm = __ballot(in && ((digit >> b) & 1u));
+                same &= (digit >> b) & 1u ? bm : ~bm;
+            }
+            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (in) {
+                const uint32_t at = hist[digit];
+                out[at + rank] = e;
+                if (rank + 1u == (uint32_t)__popcll(same)) hist[digit] = at + rank + 1u;   /* the group's last lane moves the position on */
+            }
+        }
+        __syncthreads();
+        E *t = src;
+        src = out;
+        out = t;
     }
-    uint32_t incl = cnt;
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += up;
+    /* src holds the sorted elements.  Every wave walks its share again, 64 positions at a time (a share starts on a
+     * multiple of 64, and a run ends at every multiple of 64 hits: runs never leave their group of 64).  A head is a
+     * position where the key changes or a group starts; first the heads are counted for the run numbers ... */
+    uint32_t cnt = 0;
+    for (uint32_t i0 = c_lo; i0 < c_hi; i0 += WAVE) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const bool in = i < c_hi;
+        const bool head = in && (lane == 0 || sort_key_of(src[i]) != sort_key_of(src[i - 1u]));
+        cnt += (uint32_t)__popcll(__ballot(head));
     }
-    if (lane == WAVE - 1) s_part[wid] = incl;
+    if (lane == 0) s_part[wid] = cnt;
     __syncthreads();
-    uint32_t pos = n_runs + incl - cnt, total = 0;
-    for (int w = 0; w < SORT_THREADS / WAVE; w++) {
+    uint32_t pos = n_runs, total = 0;
+    for (int w = 0; w < SORT_WAVES; w++) {
         const uint32_t v = s_part[w];
         if (w < wid) pos += v;
         total += v;
     }
-    const uint32_t pos0 = pos;          /* index of this thread's first head; the run before it holds its leading positions */
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++)
-        if ((heads >> k) & 1u) {
+    /* ... then every head writes its run {key number | hits - 1, first hit | marker}: the hits of the run are the
+     * lanes up to the next head, the marker is set when one of them carries it (rare: degenerate geometry); the
+     * payloads go to the second list in sorted order (consecutive lanes, consecutive places) */
+    for (uint32_t i0 = c_lo; i0 < c_hi; i0 += WAVE) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const bool in = i < c_hi;
+        const E e = src[in ? i : c_lo];
+        const bool head = in && (lane == 0 || sort_key_of(e) != sort_key_of(src[i - 1u]));
+        oslamk_pay py;
+        py.theta_t22 = 0;
+        py.idx = 0;
+        if (in) {
+            py = spay[sort_idx_of(e)];
+            dst[i] = py;
+        }
+        const unsigned long long hm = __ballot(head), im = __ballot(in), mm = __ballot(in && py.theta_t22 == PC_T22_FORCE);
+        if (head) {
+            const unsigned long long above = lane == WAVE - 1 ? 0ull : hm & ~((2ull << lane) - 1ull);   /* heads after this one */
+            const unsigned long long upto = above ? (1ull << (__ffsll((long long)above) - 1)) - 1ull : ~0ull;
+            const unsigned long long mine = upto & ~((1ull << lane) - 1ull) & im;                       /* the lanes of this run */
             oslamk_run rn;
-            rn.slot_r = key[k];
-            rn.first = seg + i0 + k;
-            runs[pos++] = rn;
+            rn.slot_r = sort_key_of(e) | (((uint32_t)__popcll(mine) - 1u) << OSLAMK_RUN_SHIFT);
+            rn.first = (seg + i) | ((mm & mine) ? 0x80000000u : 0u);
+            runs[pos + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = rn;
         }
-    __threadfence_block();
-    __syncthreads();                    /* the run heads are written; the LDS arrays are reused by the next segment */
-    /* bit 31 of `first`: some hit of the run carries the marker (rare: degenerate geometry) */
-    if (marked) {
-        uint32_t ri = pos0 - 1u;
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            ri += (heads >> k) & 1u;
-            if ((marked >> k) & 1u) atomicOr(&runs[ri].first, 0x80000000u);
-        }
+        pos += (uint32_t)__popcll(hm);
     }
-    /* length of every run = distance to the next head (or to the end of the segment) */
-    for (uint32_t u = (uint32_t)tid; u < total; u += SORT_THREADS) {
-        const uint32_t f0 = runs[n_runs + u].first & 0x7fffffffu;
-        const uint32_t f1 = u + 1 < total ? runs[n_runs + u + 1].first & 0x7fffffffu : seg + n;
-        runs[n_runs + u].slot_r |= (f1 - f0 - 1u) << OSLAMK_RUN_SHIFT;
-    }
+    __syncthreads();                    /* src (LDS) has been read by everybody before the next segment overwrites it */
     return total;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 {
-    __shared__ union {
-        typename hit_block_sort::storage_type big;
-        typename hit_block_sort_small::storage_type small;
-    } s_sort;
-    __shared__ uint32_t s_part[SORT_THREADS / WAVE];
-    __shared__ uint32_t s_last[SORT_THREADS];           /* the last key of every thread's sorted positions */
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[2 * SORT_SEG32];
+    __shared__ uint32_t s_hist[SORT_WAVES * SORT_RADIX];
+    __shared__ uint32_t s_part[SORT_WAVES + 1];
     const int ref_local = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
     const size_t off = a.hit_off[ref_local];
     const uint32_t cap = a.hit_off[ref_local + 1] - a.hit_off[ref_local];
     const uint32_t n_all = a.hit_count[ref_local] < cap ? a.hit_count[ref_local] : cap;     /* never past the list (oslamk_counters.list_overflow) */
     const unsigned bits = a.table.id_bits;
+    const bool wide = bits + SORT_IDX_BITS > 32u;
+    const uint32_t seg_max = wide ? SORT_SEG64 : SORT_SEG32;
     uint32_t n_runs = 0;                /* the same value in every thread */
-    for (uint32_t seg = 0; seg < n_all; seg += SORT_MAX) {
-        const uint32_t n = n_all - seg < SORT_MAX ? n_all - seg : SORT_MAX;
-        if (n <= SORT_SMALL_ITEMS * SORT_THREADS)
-            n_runs += sort_segment<SORT_SMALL_ITEMS, hit_block_sort_small>(s_sort.small, s_part, s_last, a.hit_key + off + seg,
-                                                                           a.hit_pay + off + seg, a.hit_sorted + off + seg,
-                                                                           a.runs + off, n, seg, n_runs, bits, tid, lane, wid);
+    for (uint32_t seg = 0; seg < n_all; seg += seg_max) {
+        const uint32_t n = n_all - seg < seg_max ? n_all - seg : seg_max;
+        if (!wide)
+            n_runs += sort_segment<uint32_t, SORT_SEG32>(s_buf, s_buf + SORT_SEG32, s_hist, s_part, a.hit_key + off + seg,
+                                                         a.hit_pay + off + seg, a.hit_sorted + off + seg, a.runs + off, n, seg,
+                                                         n_runs, bits, tid, lane, wid);
         else
-            n_runs += sort_segment<SORT_ITEMS, hit_block_sort>(s_sort.big, s_part, s_last, a.hit_key + off + seg,
-                                                               a.hit_pay + off + seg, a.hit_sorted + off + seg, a.runs + off, n,
-                                                               seg, n_runs, bits, tid, lane, wid);
+            n_runs += sort_segment<unsigned long long, SORT_SEG64>(reinterpret_cast<unsigned long long *>(s_buf),
+                                                                   reinterpret_cast<unsigned long long *>(s_buf) + SORT_SEG64, s_hist,
+                                                                   s_part, a.hit_key + off + seg, a.hit_pay + off + seg,
+                                                                   a.hit_sorted + off + seg, a.runs + off, n, seg, n_runs, bits, tid,
+                                                                   lane, wid);
     }
     if (tid == 0) a.run_count[ref_local] = n_runs;
 }
@@ -152,6 +185,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
 int oslamk_sort_hits(const oslamk_vote_args *a, void *stream)
 {
     if (a->n_launch <= 0) return 0;
-    hipLaunchKernelGGL(k_sort_hits, dim3((unsigned)a->n_launch), dim3(1024), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(k_sort_hits, dim3((unsigned)a->n_launch), dim3(SORT_THREADS), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }

@@ -16,14 +16,38 @@ MIN_BLOCK = 256       # smallest all-gather block, in records (4 KiB)
 
 
 def make_comm(device_index):
-    """RCCL communicator for oslam_align_multi: rank 0's id travels through torch.distributed (any
-    backend), then every rank joins with ncclCommInitRank inside the library."""
+    """RCCL communicator for oslam_align_multi: rank 0's id travels through torch.distributed (any backend), then
+    every rank joins with ncclCommInitRank inside the library.  Every rank enters the same two collectives whatever
+    fails where: rank 0 ALWAYS broadcasts (the id, or None when it could not make one), and a MIN all-reduce
+    tells every rank whether all of them have a communicator.  Returns (comm, None) or (None, reason) -- the same
+    kind on every rank."""
+    import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    box = [ppf.Comm.unique_id() if rank == 0 else None]
+    box, why = [None], None
+    if rank == 0:
+        try:
+            box[0] = ppf.Comm.unique_id()
+        except Exception as e:                      # noqa: BLE001 -- sent on as None
+            why = "rank 0: %s" % e
     dist.broadcast_object_list(box, src=0)
-    return ppf.Comm(box[0], rank, world, device_index)
+    comm = None
+    if box[0] is not None:
+        try:
+            comm = ppf.Comm(box[0], rank, world, device_index)
+        except Exception as e:                      # noqa: BLE001 -- agreed on below
+            why = "rank %d: %s" % (rank, e)
+    elif why is None:
+        why = "rank 0 could not make a communicator id"
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None, why or "another rank could not join the communicator"
+    return comm, None
 
 
 def align_multi(model, scene, comm):
@@ -97,31 +121,45 @@ def finish_on_host(cells, global_max, m_pts, m_nrm, s_pts, s_nrm, d_dist, vote_c
     return T, buf
 
 
-def register_database_by_model(models, scene, device):
+def register_database_by_model(models, scene, device, n_total=None, comm=None):
     """The other way to use several GPUs on a large model database (SURVEY 8e's alternative): the MODELS are
     dealt to the ranks, every rank registers its share against the whole scene (ppf.Database: one scene pass
     per d_dist group) and only the 4x4 poses travel.  `models`: this rank's ppf.Model objects, model j of the
-    database living on rank j % world; `scene`: unsharded.  Returns poses [n_total, 4, 4] on every rank."""
+    database living on rank j % world; `scene`: unsharded.  Returns poses [n_total, 4, 4] on every rank.
+
+    With a communicator (ppf.Comm: RCCL, or the loopback of the tests) the whole thing is one C call,
+    oslam_db_align_multi.  Without one the poses travel through torch.distributed (gloo on CPUs); a rank without
+    models still enters every collective."""
     import torch
     import torch.distributed as dist
 
-    world, rank = dist.get_world_size(), dist.get_rank()
-    db = ppf.Database(models)
-    T, _ = db.align(scene)
-    db.close()
+    if comm is not None:
+        db = ppf.Database(models) if len(models) else None
+        try:
+            T, found = ppf.db_align_multi(db, scene, comm, n_total)
+        finally:
+            if db is not None:
+                db.close()
+        return T[found != 0] if n_total is None else T
+    world = dist.get_world_size()
+    T = np.zeros((0, 4, 4), np.float32)
+    if len(models):
+        db = ppf.Database(models)
+        T, _ = db.align(scene)
+        db.close()
     n_max = torch.tensor([len(models)], dtype=torch.int64, device=device)
     dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
     block = int(n_max.item())
-    send = torch.zeros(block * 17, dtype=torch.float32, device=device)
+    send = torch.zeros(max(1, block * 17), dtype=torch.float32, device=device)
     if len(models):
         flat = np.concatenate([np.ones((len(models), 1), np.float32), T.reshape(len(models), 16)], axis=1)
         send[: flat.size] = torch.from_numpy(flat.reshape(-1)).to(device)
-    recv = torch.zeros(world * block * 17, dtype=torch.float32, device=device)
+    recv = torch.zeros(world * max(1, block * 17), dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(recv, send)
-    rec = recv.cpu().numpy().reshape(world, block, 17)
+    rec = recv.cpu().numpy().reshape(world, -1)[:, : block * 17].reshape(world, block, 17)
     out = []
     for k in range(block):                       # model j = k * world + r lives on rank r as its k-th
         for r in range(world):
             if rec[r, k, 0] == 1.0:
                 out.append(rec[r, k, 1:].reshape(4, 4))
-    return np.array(out, np.float32)
+    return np.array(out, np.float32).reshape(-1, 4, 4)

@@ -520,6 +520,19 @@ class Comm:
             pass
 
 
+def kernel_source_hash():
+    """One hash over every file the device code is built from (kernels, their headers, the Makefile with its
+    flags).  bench.py quotes PMC passes on file only for exactly this source; tools/make_pmc_traffic.py records it."""
+    import hashlib
+    d = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")) or name == "Makefile":
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def release_scratch(dev=0):
     _check(lib().oslam_release_scratch(int(dev)))
 

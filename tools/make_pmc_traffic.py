@@ -32,10 +32,12 @@ def main():
         run[k] = {"launches": f[k][0], "FETCH_SIZE_KiB_avg": f[k][1], "WRITE_SIZE_KiB_avg": w.get(k, (0, 0.0))[1]}
     v = run["k_vote"]
     run["hbm_bytes_per_vote_launch"] = 1024.0 * (2.0 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"])
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "objective-slam_amd", "csrc", "oslam_kernels.hip")
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sha = importlib.import_module("objective-slam_amd").ppf.kernel_source_hash()
     rec = {"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "),
            # bench.py reports the traffic figure only for the kernel source it was measured with
-           "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "runs": [run]}
+           "kernel_source_sha16": sha, "runs": [run]}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(run, indent=1))
 
