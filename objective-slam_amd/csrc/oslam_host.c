@@ -552,7 +552,7 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
          * its entries (oslamk_entries.pw / .puv); the uv in bucket order are not needed after that */
         HIPCHK(hipMalloc((void **)&m->ent.pw, sizeof(uint32_t) * n_pairs));
         HIPCHK(hipMalloc((void **)&m->ent.puv, sizeof(oslamk_uv) * n_pairs));
-        HIPCHK(hipMalloc((void **)&m->ent.pdir, sizeof(uint16_t) * (n_pairs + 256)));
+        HIPCHK(hipMalloc((void **)&m->ent.pdir, sizeof(uint16_t) * ((n_pairs + 256) << OSLAMK_PDIR_SHIFT)));
         KCHK(oslamk_bucket_psort(m->table, m->ent, g_stream));
         HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
         (void)hipFree(m->ent.uv);
@@ -689,7 +689,7 @@ int oslam_model_save(const oslam_model *m, const char *path)
     if (rc == OSLAM_OK) rc = db_write_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.pw, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.puv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
-    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.pdir, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_write_dev(f, m->ent.pdir, sizeof(uint16_t) * ((size_t)hd.n_entries << OSLAMK_PDIR_SHIFT), &sum);
     if (rc != OSLAM_OK) goto done;
     hd.checksum = sum;
     if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&hd, sizeof hd, 1, f) != 1) rc = fail(OSLAM_E_INVALID, "short write");
@@ -783,7 +783,7 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     if (hd.has_uv) {
         HIPCHK(hipMalloc((void **)&m->ent.pw, sizeof(uint32_t) * n_pairs));
         HIPCHK(hipMalloc((void **)&m->ent.puv, sizeof(oslamk_uv) * n_pairs));
-        HIPCHK(hipMalloc((void **)&m->ent.pdir, sizeof(uint16_t) * (n_pairs + 256)));
+        HIPCHK(hipMalloc((void **)&m->ent.pdir, sizeof(uint16_t) * ((n_pairs + 256) << OSLAMK_PDIR_SHIFT)));
     }
     HIPCHK(hipMemcpy(m->table.slots, h_slots, sizeof(oslamk_slot) * n_slots, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->ent.e4, (int)PC_ROW_SINK, n_pairs + 256, (hipStream_t)g_stream));
@@ -794,7 +794,7 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     if (rc == OSLAM_OK) rc = db_read_dev(f, m->ent.mi, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.pw, sizeof(uint32_t) * (size_t)hd.n_entries, &sum);
     if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.puv, sizeof(oslamk_uv) * (size_t)hd.n_entries, &sum);
-    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.pdir, sizeof(uint16_t) * (size_t)hd.n_entries, &sum);
+    if (rc == OSLAM_OK && hd.has_uv) rc = db_read_dev(f, m->ent.pdir, sizeof(uint16_t) * ((size_t)hd.n_entries << OSLAMK_PDIR_SHIFT), &sum);
     if (rc != OSLAM_OK) goto done;
     if (sum != hd.checksum) { rc = fail(OSLAM_E_INVALID, "model file checksum mismatch"); goto done; }
     m->h_slots = h_slots;                         /* the bucket tap reads it */
@@ -828,7 +828,7 @@ int oslam_model_info(const oslam_model *m, size_t *n_points, float *d_dist, uint
         *table_bytes = sizeof(oslamk_slot) * (uint64_t)m->table.cap * (uint64_t)m->table.n_slices +
                        sizeof(uint32_t) * (uint64_t)m->table.ucap + sizeof(uint32_t) * (OSLAMK_REACH_BINS / 32) +
                        sizeof(oslamk_uinfo) * (uint64_t)m->table.uinfo_stride * (uint64_t)m->table.n_slices +
-                       (uint64_t)m->n_entries * (4 + 2 + (m->ent.pw ? 14 : 0)) + 24ull * (uint64_t)m->c.n;
+                       (uint64_t)m->n_entries * (4 + 2 + (m->ent.pw ? 12 + (2 << OSLAMK_PDIR_SHIFT) : 0)) + 24ull * (uint64_t)m->c.n;
     return OSLAM_OK;
 }
 
@@ -870,7 +870,7 @@ static int scene_create_any(const float *xyz, const float *nrm, size_t stride_by
     *out = NULL;
     if (!(d_dist >= 0.0f) || df == 0) return fail(OSLAM_E_INVALID, "bad scene arguments");
     if (n < 2) return fail(OSLAM_E_INVALID, "scene needs at least 2 points");
-    if (n > 0x7fffffffu) return fail(OSLAM_E_LIMIT, "scene too large");
+    if (n > (1u << 28)) return fail(OSLAM_E_LIMIT, "scene larger than 2^28 points");
     if (params) p = *params; else oslam_params_default(&p);
     if (p.shard_world < 1 || p.shard_rank < 0 || p.shard_rank >= p.shard_world) return fail(OSLAM_E_INVALID, "bad shard");
     s = (oslam_scene *)calloc(1, sizeof *s);

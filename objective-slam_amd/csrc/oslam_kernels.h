@@ -50,18 +50,22 @@ typedef struct oslamk_entries {
      * a test per vote; only those (one vote in 4000) are re-evaluated with the reference's float sequence. */
     uint32_t *pw;
     oslamk_uv *puv;
-    /* directory of that order: a segment of n entries at bucket offset b is cut into K = oslamk_pdir_cells(n) cells of
-     * equal width in P (one or two entries each on average); pdir[b + k], k = 0 .. K, is the position inside the
+    /* directory of that order: a segment of n entries at bucket offset b is cut into K = OSLAMK_PDIR_CELLS(n) cells of
+     * equal width in P (one or two entries each on average); pdir[(b << OSLAMK_PDIR_SHIFT) + k], k = 0 .. K, is the position inside the
      * segment of the first entry whose cell is >= k (pdir[b + K] = n).  The search for a hit's near-edge entries is two
      * 2-byte loads and the one or two cells between them, not a binary search. */
     uint16_t *pdir;
 } oslamk_entries;
 #define OSLAMK_PSEG 4096       /* entries per sorted segment of a bucket (one LDS sort) */
-/* cells of a segment of n entries: the largest power of two below n (at least 1), so that K + 1 directory places fit the
- * n places the segment owns in pdir (a bucket is padded to a multiple of 4 entries: a segment of one still has two) */
-#define OSLAMK_PDIR_CELLS(n) ((n) <= 1u ? 1u : 1u << (31 - __builtin_clz((n) - 1u)))
+/* cells of a segment of n entries: the largest power of two below the n << OSLAMK_PDIR_SHIFT directory places the
+ * segment owns (so that K + 1 places fit; a bucket is padded to a multiple of 4 entries, so a segment of one still has
+ * two), at most 4096: a cell must not be narrower than the margin window (2^32 / 4096 > PC_T24_EDGE) */
+#ifndef OSLAMK_PDIR_SHIFT
+#define OSLAMK_PDIR_SHIFT 0
+#endif
+#define OSLAMK_PDIR_CELLS_RAW(m) ((m) <= 1u ? 1u : 1u << (31 - __builtin_clz((m) - 1u)))
+#define OSLAMK_PDIR_CELLS(n) (OSLAMK_PDIR_CELLS_RAW((n) << OSLAMK_PDIR_SHIFT) > 4096u ? 4096u : OSLAMK_PDIR_CELLS_RAW((n) << OSLAMK_PDIR_SHIFT))
 
-/* A cloud in HBM: structure of arrays. */
 typedef struct oslamk_cloud {
     const float *px, *py, *pz, *nx, *ny, *nz;
     int n;
@@ -217,6 +221,8 @@ int oslamk_scene_hits(const oslamk_vote_args *a, void *stream);
 int oslamk_sort_hits(const oslamk_vote_args *a, void *stream);
 /* votes of the same batch (needs the sorted hit lists) */
 int oslamk_vote(const oslamk_vote_args *a, void *stream);
+/* the two re-vote passes over the launch's redo list (called by oslamk_vote) */
+int oslamk_vote_wide(const oslamk_vote_args *a, void *stream);
 
 /* voxel grid (oslam_voxel.hip): out6 = device [n][6] (x y z nx ny nz per voxel); returns a
  * hipError_t, or -1 when the voxel count overflows int32 */

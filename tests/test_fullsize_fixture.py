@@ -63,3 +63,27 @@ def test_bench_registration_equals_the_oracle_cell_for_cell(ppf, built_lib, synt
         assert hashlib.sha256(np.ascontiguousarray(poses, np.float32).tobytes()).hexdigest() == str(z["poses_sha256"]), (tag, par)
         assert np.array_equal(T, z["T_" + tag]), (tag, par)
         mo.close()
+
+
+@pytest.mark.gpu
+def test_bench_registration_in_batches_equals_the_single_launch(ppf, built_lib, synth):
+    """GPU: the same registration with the hit-list pool limited to 2 GiB (oslam_params.scratch_gib): the 12 500
+    reference points no longer fit one launch (they need 4.3 GB) and are voted in batches -- same cells, same counters,
+    same pose as the oracle's, and the pool keeps its size from one registration to the next."""
+    z = np.load(FIXTURE)
+    mp, mn, sp, sn, d = _workload(synth, z)
+    ppf.release_scratch(0)          # whatever earlier registrations left: the pool only ever grows
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=int(z["df"]))
+    mo = ppf.Model(mp, mn, d_dist=d, params=ppf.default_params(scratch_gib=2))
+    pool = []
+    for _ in range(2):
+        T = mo.ppf_lookup(sc)
+        cells, _ = mo.last_cells()
+        assert mo.stats["vote_launches"] >= 2
+        assert np.array_equal(cells["code"], z["cell_code"]) and np.array_equal(cells["count"], z["cell_count"])
+        assert int(mo.stats["num_votes"]) == int(z["stats"][2]) and int(mo.stats["num_hits"]) == int(z["stats"][1])
+        assert np.array_equal(T, z["T_gpu"])
+        pool.append(mo.stats["scratch_bytes"])
+    assert pool[0] == pool[1] <= (2 << 30) + (1 << 20)
+    mo.close()
+    ppf.release_scratch(0)          # the next test gets the default pool again

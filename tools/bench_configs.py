@@ -43,7 +43,7 @@ def cfg2():
     st = mo.stats
     return {"config": "cfg2: 5k model vs voxel-gridded scene", "scene_points_after_voxel_grid": len(sp), "voxel_grid_s": t_vox,
             "ref_point_df": 5, "align_s": el, "scene_ppfs_per_s": st["num_scene_ppfs"] / el, "votes_per_s": st["num_votes"] / el,
-            "found": found_at_reference_criterion(T, poses[0][1], mp)}
+            "wide_workgroups": st["wide_workgroups"], "found": found_at_reference_criterion(T, poses[0][1], mp)}
 
 
 def cfg3():
@@ -120,16 +120,19 @@ def cfg5(n_models=4, frames=8):
         imgs.append(synth.render_depth(np.concatenate(pts), background_z=10.0, splat=1))
         truths.append(tr)
     leaf = min(dd)                                                 # one scene_leaf_size for all models (alignment.cpp:265-271)
+    wide = 0
     def one(img):
         t0 = time.perf_counter()
         # depth -> points + normals -> voxel grid -> scene in one call (d_dist 0: a scene for every model)
         sc = ppf.Scene.from_depth(img, 525.0, 525.0, 319.5, 239.5, leaf=leaf, d_dist=0.0, ref_point_downsample_factor=2,
                                   z_min=0.5, z_max=12.0, max_jump=0.08)
         t1 = time.perf_counter()
+        nonlocal wide
         out, votes = [], 0
         for mo in models:
             out.append(mo.ppf_lookup(sc, allow_no_votes=True).copy())
             votes += mo.stats["num_votes"]
+            wide += mo.stats["wide_workgroups"]
         n_scene = sc.numPoints()
         sc.close()
         t2 = time.perf_counter()
@@ -141,10 +144,92 @@ def cfg5(n_models=4, frames=8):
             "frames": frames, "frames_per_s": frames / el, "ms_per_frame": 1e3 * el / frames,
             "ms_depth_to_scene": 1e3 * np.mean([r[1] for r in res]),
             "ms_registration_all_models": 1e3 * np.mean([r[6] for r in res]), "votes_per_frame": int(np.mean([r[7] for r in res])),
-            "scene_points_after_voxel_grid": int(np.mean([r[5] for r in res])),
+            "scene_points_after_voxel_grid": int(np.mean([r[5] for r in res])), "wide_workgroups_per_frame": wide / float(frames + 1),
             "objects_found": "%d of %d" % (ok, 2 * frames)}
+
+
+def _planes_and_object(n, rng, extent, obj_id=0, obj_frac=0.25):
+    """A floor (z = 0), a wall (x = 0) and a table top (z = 0.8) of `extent`, with an object standing on the table: the
+    kind of cloud a depth camera sees indoors.  Large planes in BOTH clouds put more than 65 535 votes into single
+    accumulator cells (every in-plane pair has the same feature), which is what the 32-bit re-vote passes exist for."""
+    n_obj = int(n * obj_frac)
+    n_pl = (n - n_obj) // 3
+    u = rng.uniform(0, extent, (3, n_pl, 2))
+    floor = np.concatenate([u[0], np.zeros((n_pl, 1))], 1)
+    wall = np.concatenate([np.zeros((n_pl, 1)), u[1]], 1)
+    table = np.concatenate([0.3 * extent + 0.4 * u[2], np.full((n_pl, 1), 0.8)], 1)
+    op, on = synth.make_model(obj_id, n - 3 * n_pl)
+    op = op * (0.25 * extent / synth.bbox_extent(op)) + np.array([0.5 * extent, 0.5 * extent, 0.8 + 0.2 * extent])
+    pts = np.concatenate([floor, wall, table, op]).astype(np.float32)
+    nrm = np.concatenate([np.tile([0, 0, 1.0], (n_pl, 1)), np.tile([1.0, 0, 0], (n_pl, 1)), np.tile([0, 0, 1.0], (n_pl, 1)), on]).astype(np.float32)
+    order = rng.permutation(len(pts))
+    return np.ascontiguousarray(pts[order]), np.ascontiguousarray(nrm[order])
+
+
+def planes(M=5000, S=100000, df=8):
+    """The re-vote path where it matters: a plane-dominated model (object on a table in a room corner) against a
+    plane-dominated scene of the same room.  Reports wide_workgroups and the time per registration."""
+    rng = np.random.default_rng(7)
+    mp, mn = _planes_and_object(M, rng, 3.5)
+    sp0, sn0 = _planes_and_object(S, rng, 3.5)
+    R = synth.random_rotation(synth.SplitMix64(5))
+    sp = (sp0 @ R.T + np.float32([0.4, -0.2, 0.1])).astype(np.float32)
+    sn = (sn0 @ R.T).astype(np.float32)
+    sp += (0.002 * rng.normal(size=sp.shape)).astype(np.float32)
+    d = synth.d_dist_for(mp, 0.025)
+    mo = ppf.Model(mp, mn, d_dist=d)
+    sc = ppf.Scene(sp, sn, d_dist=d, ref_point_downsample_factor=df)
+    mo.ppf_lookup(sc, allow_no_votes=True)
+    t = time.perf_counter(); T = mo.ppf_lookup(sc, allow_no_votes=True); el = time.perf_counter() - t
+    st = mo.stats
+    Tt = np.eye(4); Tt[:3, :3] = R; Tt[:3, 3] = [0.4, -0.2, 0.1]
+    dt, dr = ppf.ht_dist(T, Tt)
+    return {"config": "plane-dominated model (%d points) vs plane-dominated scene (%d points): floor + wall + table + object in both" % (M, S),
+            "ref_point_df": df, "align_s": el, "ms_vote_kernels": st["ms_vote_kernel"], "ms_key_kernels": st["ms_key_kernel"],
+            "votes": st["num_votes"], "max_cell": st["max_count"], "wide_workgroups": st["wide_workgroups"],
+            "vote_workgroups": int(st["num_scene_ppfs"] // (S - 1)) * ((M + 2045) // 2046), "votes_per_s": st["num_votes"] / el,
+            "rot_err_deg": float(np.degrees(dr)), "trans_err": float(dt)}
+
+
+def db50(frames=10):
+    """configs[4] at database size (tests/test_gpu_database.py measures the same): 640x480 depth frames against 50
+    models with one d_dist -- all 50 on one GPU, and the 7 models one of 8 GPUs holds when the database is split by model."""
+    n_models, world = 50, 8
+    raw = [synth.make_model(k, 1500) for k in range(n_models)]
+    d = synth.d_dist_for(raw[0][0], 0.05)
+    grids = [ppf.voxel_grid(c[0], c[1], leaf=d) for c in raw]
+    dense, _ = synth.make_model(0, 300000)
+    rng = synth.SplitMix64(93)
+    imgs = []
+    for f in range(frames):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = synth.random_rotation(rng)
+        T[:3, 3] = [0.5 * np.cos(0.7 * f), 0.3 * np.sin(0.7 * f), 5.5 + 0.1 * f]
+        imgs.append(synth.render_depth(dense @ T[:3, :3].T + T[:3, 3], background_z=9.0, splat=1))
+    out = {"config": "cfg5 at database size: 640x480 depth frames vs a 50-model database, one d_dist", "frames": frames}
+    for name, ids in (("all_50_on_one_gpu", list(range(n_models))), ("shard_of_7_models", list(range(0, n_models, world)))):
+        models = [ppf.Model(grids[j][0], grids[j][1], d_dist=d) for j in ids]
+        db = ppf.Database(models)
+        def frame(img):
+            sc = ppf.Scene.from_depth(img, 525.0, 525.0, 319.5, 239.5, leaf=d, d_dist=0.0, ref_point_downsample_factor=4,
+                                      z_min=0.5, z_max=12.0, max_jump=0.08)
+            T, stats = db.align(sc)
+            n = sc.numPoints()
+            sc.close()
+            return stats, n
+        frame(imgs[0])
+        t = time.perf_counter(); res = [frame(im) for im in imgs]; el = time.perf_counter() - t
+        out[name] = {"frames_per_s": frames / el, "ms_per_frame": 1e3 * el / frames, "scene_points": res[0][1],
+                     "ms_key_kernels": float(np.mean([sum(s["ms_key_kernel"] for s in r[0]) for r in res])),
+                     "ms_vote_kernels": float(np.mean([sum(s["ms_vote_kernel"] for s in r[0]) for r in res])),
+                     "wide_workgroups_per_frame": float(np.mean([sum(s["wide_workgroups"] for s in r[0]) for r in res])),
+                     "model_points": int(np.mean([len(grids[j][0]) for j in ids]))}
+        db.close()
+        for m in models:
+            m.close()
+    return out
 
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-    print(json.dumps({"cfg2": cfg2, "cfg3": cfg3, "cfg3db": cfg3db, "cfg4": cfg4, "cfg5": cfg5}[which]()), flush=True)
+    print(json.dumps({"cfg2": cfg2, "cfg3": cfg3, "cfg3db": cfg3db, "cfg4": cfg4, "cfg5": cfg5, "planes": planes, "db50": db50}[which]()), flush=True)
