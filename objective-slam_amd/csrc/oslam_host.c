@@ -530,6 +530,7 @@ int oslam_model_create(const float *xyz, const float *nrm, size_t n, size_t stri
     HIPCHK(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
     if (h_small[64]) { rc = fail(OSLAM_E_LIMIT, "union key table overflow"); goto done; }
     m->n_entries = h_small[65];
+    m->ent.n_real = m->n_entries;
     m->num_model_keys = (uint64_t)h_small[66] + 1;    /* + the key-0 bucket of the n self pairs */
     n_pairs = m->n_entries ? m->n_entries : 1;
 
@@ -773,6 +774,7 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     m->table.ucap = hd.ucap;
     m->table.ushift = hd.ushift;
     m->n_entries = hd.n_entries;
+    m->ent.n_real = hd.n_entries;
     m->num_model_keys = hd.num_model_keys;
     n_pairs = hd.n_entries ? hd.n_entries : 1;
     HIPCHK(hipMalloc((void **)&m->table.slots, sizeof(oslamk_slot) * n_slots));
@@ -1285,7 +1287,11 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
     HIPCHK(hipStreamSynchronize(st));
     for (j = 0; j < nm; j++)
         if (cnt[j].list_overflow) {
-            rc = fail(OSLAM_E_DEVICE, "a hit list overflowed: the counting pass and the hit pass disagreed on the pairs within reach");
+            rc = fail(OSLAM_E_DEVICE, cnt[j].list_overflow & 1u
+                          ? "a hit list overflowed: the counting pass and the hit pass disagreed on the pairs within reach"
+                          : cnt[j].list_overflow & 2u ? "near-edge search: a hit's key number lies outside the model's bucket records"
+                          : cnt[j].list_overflow & 4u ? "near-edge search: a bucket lies outside the model's entry arrays"
+                                                      : "near-edge search: a directory place lies outside its bucket segment");
             goto done;
         }
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, ev[0], ev[1]));
@@ -1381,7 +1387,7 @@ static int vote_and_fetch(scratch_pool *pool, oslam_model *m, oslam_scene *s, os
     }
     if (getenv("OSLAM_PROF"))      /* only a -DVOTE_PROF build fills these */
         fprintf(stderr, "[oslam prof] k_vote wave cycles: pre-scan %llu, voting %llu, wait at the barrier behind it %llu, "
-                        "peak extraction %llu\n",
+                        "of the voting: near-edge search %llu\n",
                 cnt->prof[0], cnt->prof[1], cnt->prof[2], cnt->prof[3]);
     *n_cells = cnt->out_count;
     /* the records stay in HBM when the pose tail runs there (leave_on_device_from = its lower bound, 0 = never) */

@@ -55,6 +55,8 @@ typedef struct oslamk_entries {
      * segment of the first entry whose cell is >= k (pdir[b + K] = n).  The search for a hit's near-edge entries is two
      * 2-byte loads and the one or two cells between them, not a binary search. */
     uint16_t *pdir;
+    uint32_t n_real;           /* entries the arrays hold (the end of the last bucket, padding included): what the near-edge
+                                * search checks its indices against before it loads */
 } oslamk_entries;
 #define OSLAMK_PSEG 4096       /* entries per sorted segment of a bucket (one LDS sort) */
 /* cells of a segment of n entries: the largest power of two below the n << OSLAMK_PDIR_SHIFT directory places the
@@ -120,7 +122,8 @@ typedef struct oslamk_counters {
     unsigned long long entries;   /* model pair entries streamed: sum of the bucket lengths over (run, slice) */
     unsigned long long items;     /* (run, slice) pairs with a bucket */
     unsigned long long prof[4];   /* -DVOTE_PROF builds: k_vote wave cycles (pre-scan, voting, wait at the barrier behind it, peak extraction) */
-    uint32_t list_overflow;       /* a hit list was too short for its hits (the counting and the hit kernel disagreed): the call fails */
+    uint32_t list_overflow;       /* bit 0: a hit list was too short for its hits (the counting and the hit kernel disagreed); bits 1..3: the
+                                   * near-edge search met a key number, a bucket or a directory place out of range.  The call fails */
     uint32_t pad_;
 } oslamk_counters;
 
@@ -195,7 +198,8 @@ typedef struct oslamk_vote_args {
     /* Hit lists of the batch, sized by demand: reference point ref_local owns the slots
      * hit_off[ref_local] .. hit_off[ref_local + 1] of every array below; the size is the number of its
      * scene pairs whose distance bin can reach a model key (oslamk_scene_count), an upper bound of its hits.
-     *   hit_key / hit_pay : hits in arrival order (oslamk_scene_hits): union-table slot of the key, payload
+     *   hit_key / hit_pay : hits in arrival order (oslamk_scene_hits): number of the key, payload; oslamk_sort_hits
+     *                       overwrites hit_key with the key numbers in SORTED order | run-holds-a-marker << 31
      *   hit_sorted        : the payloads ordered by slot (oslamk_sort_hits) -- what oslamk_vote reads
      *   runs              : runs of equal keys in hit_sorted, run_count[ref_local] of them */
     uint32_t *keep_count;      /* [n_launch] written by oslamk_scene_count (must be zero on entry) */

@@ -13,7 +13,7 @@
  * An element is key number << 14 | position in the list (one 32-bit word: two buffers of 16 384 elements fit the LDS);
  * key numbers above 18 bits (databases of many models in one group) take 64-bit elements and half the segment.  The
  * run heads (a key changes, or 64 hits are full) come from the sorted words, the payloads are gathered into the second
- * list.  A list longer than a segment is sorted in segments (a key then has one run per segment it occurs in: its
+ * list, and the sorted key numbers replace the arrival-order ones.  A list longer than a segment is sorted in segments (a key then has one run per segment it occurs in: its
  * bucket is streamed once per segment instead of once, everything else is unchanged).
  */
 #include <hip/hip_runtime.h>
@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned long long sort_pack(uint32_t key, uint32_t i
  * s_part [SORT_WAVES + 1].  Returns the segment's run count (the same value in every thread). */
 template <typename E, int SEG>
 __device__ __forceinline__ uint32_t sort_segment(E *bufA, E *bufB, uint32_t *s_hist, uint32_t *s_part, const uint32_t *skey,
-                                                 const oslamk_pay *spay, oslamk_pay *dst, oslamk_run *runs, uint32_t n,
+                                                 uint32_t *skey_out, const oslamk_pay *spay, oslamk_pay *dst, oslamk_run *runs, uint32_t n,
                                                  uint32_t seg, uint32_t n_runs, unsigned bits, int tid, int lane, int wid)
 {
     for (uint32_t i = (uint32_t)tid; i < n; i += SORT_THREADS) bufA[i] = sort_pack(skey[i], i, E());
@@ -138,14 +138,23 @@ __device__ __forceinline__ uint32_t sort_segment(E *bufA, E *bufB, uint32_t *s_h
             dst[i] = py;
         }
         const unsigned long long hm = __ballot(head), im = __ballot(in), mm = __ballot(in && py.theta_t22 == PC_T22_FORCE);
-        if (head) {
-            const unsigned long long above = lane == WAVE - 1 ? 0ull : hm & ~((2ull << lane) - 1ull);   /* heads after this one */
+        if (in) {
+            /* the lanes of this lane's run: from the last head at or below it to the next head above it */
+            const unsigned long long le = lane == WAVE - 1 ? ~0ull : (2ull << lane) - 1ull;
+            const int start = 63 - __builtin_clzll(hm & le);
+            const unsigned long long above = hm & ~le;
             const unsigned long long upto = above ? (1ull << (__ffsll((long long)above) - 1)) - 1ull : ~0ull;
-            const unsigned long long mine = upto & ~((1ull << lane) - 1ull) & im;                       /* the lanes of this run */
-            oslamk_run rn;
-            rn.slot_r = sort_key_of(e) | (((uint32_t)__popcll(mine) - 1u) << OSLAMK_RUN_SHIFT);
-            rn.first = (seg + i) | ((mm & mine) ? 0x80000000u : 0u);
-            runs[pos + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = rn;
+            const unsigned long long mine = upto & ~((1ull << start) - 1ull) & im;
+            const uint32_t marked = (mm & mine) ? 0x80000000u : 0u;
+            /* the sorted key numbers, over the arrival-order ones this segment was loaded from (they are not read
+             * again): what the vote kernel's near-edge search goes by; bit 31 = the hit's run holds a marker */
+            skey_out[i] = sort_key_of(e) | marked;
+            if (head) {
+                oslamk_run rn;
+                rn.slot_r = sort_key_of(e) | (((uint32_t)__popcll(mine) - 1u) << OSLAMK_RUN_SHIFT);
+                rn.first = (seg + i) | marked;
+                runs[pos + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = rn;
+            }
         }
         pos += (uint32_t)__popcll(hm);
     }
@@ -170,12 +179,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hits(oslamk_vote_args a)
         const uint32_t n = n_all - seg < seg_max ? n_all - seg : seg_max;
         if (!wide)
             n_runs += sort_segment<uint32_t, SORT_SEG32>(s_buf, s_buf + SORT_SEG32, s_hist, s_part, a.hit_key + off + seg,
-                                                         a.hit_pay + off + seg, a.hit_sorted + off + seg, a.runs + off, n, seg,
+                                                         a.hit_key + off + seg, a.hit_pay + off + seg, a.hit_sorted + off + seg, a.runs + off, n, seg,
                                                          n_runs, bits, tid, lane, wid);
         else
             n_runs += sort_segment<unsigned long long, SORT_SEG64>(reinterpret_cast<unsigned long long *>(s_buf),
                                                                    reinterpret_cast<unsigned long long *>(s_buf) + SORT_SEG64, s_hist,
-                                                                   s_part, a.hit_key + off + seg, a.hit_pay + off + seg,
+                                                                   s_part, a.hit_key + off + seg, a.hit_key + off + seg, a.hit_pay + off + seg,
                                                                    a.hit_sorted + off + seg, a.runs + off, n, seg, n_runs, bits, tid,
                                                                    lane, wid);
     }
