@@ -204,13 +204,14 @@ def main():
         path_bytes = 24.0 * S + 8.0 * st["num_pairs_probed"] + 8.0 * st["num_votes"] + 16.0 * st["num_emitted"]
         votes_per_s_kernel = st["num_votes"] * args.steps / (ms_vote_kernel * 1e-3)
         # ceilings of the vote loop (tools/micro/): one conflict-free ds_add_u32 wave-instruction
-        # (64 votes) per 4.4 cycles per CU (measured); one hit voting with a chunk = 256 votes = 16 vector
-        # instructions in exact mode, 13 in fast mode, at their measured issue costs (v_sub_u32 2.33 cycles per
-        # wave-instruction, everything else in the loop 4.2-4.3: tools/micro/valu_rate_bench.hip) on one of 1024
-        # SIMDs; 2.4 GHz
+        # (64 votes) per 4.4 cycles per CU (measured); one hit voting with a chunk = 256 votes = 13 vector
+        # instructions in both modes (exact mode finds its near-edge votes by search, outside the loop), at their
+        # stand-alone issue costs (v_sub_u32 2.33 cycles per wave-instruction, everything else in the loop 4.2-4.3:
+        # tools/micro/valu_rate_bench.hip) on one of 1024 SIMDs; 2.4 GHz.  In the kernel's mix the instructions issue
+        # at 4.3 cycles on average (profiles/r03_pmc_sq_k_vote.txt), which is why this fraction cannot reach 1.
         lds_peak = 256 * 64 * 2.4e9 / 4.4
-        valu_instr = 16 if mode == 0 else 13
-        valu_cycles = 60.5 if mode == 0 else 47.5
+        valu_instr = 13
+        valu_cycles = 47.5
         valu_peak = 1024 * 256 * 2.4e9 / valu_cycles
         dt, dr = ppf.ht_dist(T, poses[0][1])
         traffic, traffic_note = pmc_traffic(args, M, S, df)

@@ -343,7 +343,7 @@ int oslam_last_cells(oslam_model *m, oslam_cell *cells_out, float *poses_out, si
  * NULL = the default stream).  bench.py passes torch's current stream. */
 int oslam_set_stream(void *hip_stream);
 /* Calls that launch on one device are serialised inside the library (one lock per device: they share
- * the device's hit-list pool, which grows to what a registration needs, at most OSLAM_SCRATCH_GIB GiB,
+ * the device's hit-list pool, which grows to what a registration needs, at most oslam_params.scratch_gib GiB,
  * default 4, unless a single reference point needs more).  oslam_release_scratch frees the pool and the
  * other per-device work space; the next call allocates them again. */
 int oslam_release_scratch(int dev);

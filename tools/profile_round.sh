@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything a round's profiles/ entries come from, in one gpurun call:
-#   tools/profile_round.sh r02     (run on the GPU box from the repo root)
+#   tools/profile_round.sh r03     (run on the GPU box from the repo root)
 # bench line, rocprofv3 kernel stats of the same command, and the two PMC traffic passes.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
