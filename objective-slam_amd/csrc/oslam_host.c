@@ -758,12 +758,18 @@ int oslam_model_load(const char *path, const oslam_params *params, oslam_model *
     sum = fnv64(sum, nrm, 12 * n);
     sum = fnv64(sum, m->weights, 4 * n);
     sum = fnv64(sum, h_slots, sizeof(oslamk_slot) * n_slots);
-    /* no bucket may reach past the entry arrays */
-    for (i = 0; i < n_slots; i++)
-        if (h_slots[i].key != 0 && ((uint64_t)h_slots[i].start + h_slots[i].len > hd.n_entries || (h_slots[i].start & 3u))) {
-            rc = fail(OSLAM_E_INVALID, "model file: a bucket lies outside the entry arrays");
-            goto done;
+    /* the buckets lie one behind the other in slot order, each rounded up to four entries (k_table_scan), and none
+     * reaches past the entry arrays: the vote kernel addresses a slice's entries relative to its first slot's start */
+    {
+        uint64_t run = 0;
+        for (i = 0; i < n_slots; i++) {
+            if (h_slots[i].start != run || run + h_slots[i].len > hd.n_entries) {
+                rc = fail(OSLAM_E_INVALID, "model file: a bucket lies outside the entry arrays or out of order");
+                goto done;
+            }
+            run += ((uint64_t)h_slots[i].len + 3u) & ~(uint64_t)3u;
         }
+    }
     rc = cloud_upload(&m->c, xyz, nrm, n, 12);
     if (rc != OSLAM_OK) goto done;
     m->d_dist = hd.d_dist;
