@@ -246,15 +246,33 @@ int oslamk_aos6_to_soa(const float *d_in6, size_t n, float *d_soa, void *stream)
  * in that order; trans/quat/cell in pose order.  The translation-averaging variant stays on the host. */
 int oslamk_cluster_scores(int n, const float *trans, const float *quat, const int *cell, const uint32_t *shash,
                           const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
-                          float *score, void *stream);
+                          float *score, int whole_host, const unsigned long long *whole_dev, uint32_t *table, void *stream);
+/* table: device work space of oslamk_cluster_table_words(n) 32-bit words (the cells of the sorted list, hashed) */
+size_t oslamk_cluster_table_words(int n);
+/* whole_host / whole_dev: the weighted votes are whole numbers with a sum below 2^24 - 1 (their float sum is then exact
+ * in any order and the kernel adds them lane-parallel); whole_dev, if not NULL, points to {sum, not-whole flag} on the device */
 
 /* pose tail on the device (oslam_posegpu.hip): filter, order, poses, clustering scores, winner.
  * d_Tm16 [M][16] / d_Ts16 [ceil(S/df)][16]: the frames T_g of the model points and of the scene's
  * reference-point candidates (host libm); h_rotx_cs: oslam_rotx_table.  Returns a hipError_t, -2 = no host memory */
 int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, float min_votecount, const float *d_Tm16,
                       const float *d_Ts16, uint32_t df, const float *d_weights, const float *h_rotx_cs, float d_dist,
-                      int use_l1, oslamk_cell *d_cells_out, float *d_poses, uint32_t *n_out, uint32_t *best_out,
-                      float T_best[16], void *stream);
+                      int use_l1, oslamk_cell *d_cells_out, float *d_poses, uint32_t gmax, uint32_t model_points,
+                      uint32_t scene_points, uint32_t *n_out, uint32_t *best_out, float T_best[16], void *stream);
+/* gmax (the largest count among the records), model_points and scene_points bound the fields of a record: with few
+ * enough bits the cells are ordered by one sort of packed keys */
+
+/* The same tail in pieces, for several models in flight on one stream (a database frame): reserve once for the largest
+ * record count and the number of models, enqueue every model's selection, wait, read the counts, enqueue every model's
+ * chain (n >= 2 selected records), wait, read the results.  The chains share the work space: they run in stream order. */
+int oslamk_pose_reserve(uint32_t n_max, uint32_t slots, const float *h_rotx_cs, void *stream);
+int oslamk_pose_select_async(const oslamk_cell *d_in, uint32_t n_in, float min_votecount, oslamk_cell *d_sel, uint32_t slot,
+                             void *stream);
+uint32_t oslamk_pose_selected(uint32_t slot);
+int oslamk_pose_finish_async(uint32_t n, const oslamk_cell *d_sel, const float *d_Tm16, const float *d_Ts16, uint32_t df,
+                             const float *d_weights, float d_dist, int use_l1, oslamk_cell *d_cells_out, float *d_poses,
+                             uint32_t gmax, uint32_t model_points, uint32_t scene_points, uint32_t slot, void *stream);
+void oslamk_pose_result(uint32_t slot, uint32_t *best_out, float T_best[16]);
 
 /* records with count > min_votecount, compacted into d_out (capacity n_in); *n_out on the host */
 int oslamk_select_cells(const oslamk_cell *d_in, uint32_t n_in, float min_votecount, oslamk_cell *d_out, uint32_t *n_out,

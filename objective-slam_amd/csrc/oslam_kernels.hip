@@ -653,67 +653,135 @@ __device__ __forceinline__ uint32_t fnv_cell3(int cx, int cy, int cz)
     return pm_fnv1a_word(h, (uint32_t)cz);
 }
 
-/* One wave per pose.  The 64 lanes test 64 candidates of a neighbour cell at once (the
- * expensive part); the compatible ones are then added by walking the ballot mask in ascending
- * order, i.e. exactly the sequential float sum of the reference loop.  sq/st/sw are the pose
- * quaternions, translations and weighted votes permuted into sorted (cell hash, pose index)
- * order, so consecutive lanes read consecutive memory. */
+/* The cells of the sorted pose list as a table: cell hash -> [first, end) of its poses in sorted order (open addressing,
+ * at most half full; tab[3 * slot] = hash, 0 = empty: a hash of 0 is never searched).  Two small kernels: the first
+ * pose of every cell claims a slot and writes `first`; then the first pose of the NEXT cell (or the end of the list)
+ * finds that slot again and writes `end`. */
+__device__ __forceinline__ uint32_t cell_slot(uint32_t h, uint32_t mask) { return (h * 2654435761u) & mask; }
+
+__global__ void k_cell_table_first(const uint32_t *shash, int n, uint32_t *tab, uint32_t mask)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t h = shash[j];
+    if (h == 0u || (j > 0 && shash[j - 1] == h)) return;
+    for (uint32_t s = cell_slot(h, mask);; s = (s + 1u) & mask) {
+        const uint32_t old = atomicCAS(&tab[3u * s], 0u, h);
+        if (old == 0u) { tab[3u * s + 1u] = (uint32_t)j; return; }
+    }
+}
+
+__global__ void k_cell_table_end(const uint32_t *shash, int n, uint32_t *tab, uint32_t mask)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;     /* j = 1 .. n: the position behind a cell's last pose */
+    if (j < 1 || j > n) return;
+    const uint32_t h = shash[j - 1];
+    if (h == 0u || (j < n && shash[j] == h)) return;
+    for (uint32_t s = cell_slot(h, mask);; s = (s + 1u) & mask) {
+        const uint32_t k = tab[3u * s];
+        if (k == h) { tab[3u * s + 2u] = (uint32_t)j; return; }
+        if (k == 0u) return;                                  /* not reached: every cell was entered */
+    }
+}
+
+/* One wave per pose.  Lane c < 27 looks the neighbour cell c up in the table (the reference's (dx, dy, dz) order =
+ * ascending c; the pose's own cell is skipped, kernel.cu:684-689); the poses of the 26 cells then form one list,
+ * cell after cell, which the 64 lanes test 64 at a time -- a handful of independent loads per pose instead of 26
+ * binary searches and 26 dependent cell walks (with 5 * 10^4 poses per model of the depth-stream database the kernel
+ * sat at the latency of those chains: 0.5 ms per model).  The compatible ones are added by walking the ballot mask in
+ * ascending order, i.e. exactly the sequential float sum of the reference loop -- or, when the weighted votes are
+ * whole numbers with a small sum, lane-parallel (see `whole`).  sq/st/sw are the pose quaternions, translations and
+ * weighted votes permuted into sorted (cell hash, pose index) order, so consecutive lanes read consecutive memory. */
 __global__ __launch_bounds__(64) void k_cluster_scores(int n, const float *trans, const float *quat,
-                                                       const int *cell, const uint32_t *shash,
+                                                       const int *cell, const uint32_t *tab, uint32_t mask,
                                                        const float4 *sq, const float *st, const float *sw,
-                                                       float d_dist, int use_l1, float *score)
+                                                       float d_dist, int use_l1, float *score, int whole_host,
+                                                       const unsigned long long *whole_dev)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
+    /* Weighted votes that are all whole numbers and sum to less than 2^24 (weights of 1, the default: the votes are
+     * counts) add up exactly in float whatever the order: every partial sum is a whole number below 2^24.  Then the
+     * lanes keep their own sums and the wave adds them once -- the same bits as the reference's sequential sum, without
+     * walking the compatible poses one by one (a dense cluster has thousands per pose).  Decided by the caller for
+     * host-made input (whole_host) or by k_pose_cells on the device (whole_dev[0] = sum of the votes, [1] != 0: one
+     * of them is not whole). */
+    const bool whole = whole_dev ? (whole_dev[1] == 0ull && whole_dev[0] < (1ull << 24) - 1ull) : whole_host != 0;
+    float lane_sum = 0.0f;
     const float rot_thresh = 2 * PM_D_ANGLE, rot_thresh_sq = rot_thresh * rot_thresh;
     const float q0 = quat[4 * i], q1 = quat[4 * i + 1], q2 = quat[4 * i + 2], q3 = quat[4 * i + 3];
     const float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
     const int cx = cell[3 * i], cy = cell[3 * i + 1], cz = cell[3 * i + 2];
     float votes = 1;                                             /* kernel.cu:722 */
-    /* the 26 neighbour cells in the reference's (dx, dy, dz) order = ascending c; lane c finds the start of
-     * cell c's poses in the sorted list (26 binary searches side by side instead of one after the other:
-     * with 10^6 poses the dependent loads of the searches were most of this kernel's time) */
-    uint32_t my_h = 0;
-    int my_lo = n;
+    uint32_t first = 0, len = 0;
     if (lane < 27 && lane != 13) {
         const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
-        my_h = fnv_cell3(cx + dx, cy + dy, cz + dz);
-        if (my_h != 0) {                                          /* a hash of 0 is never searched (kernel.cu:727) */
-            int lo = 0, hi = n;
-            while (lo < hi) {
-                const int mid = lo + (hi - lo) / 2;
-                if (shash[mid] < my_h) lo = mid + 1; else hi = mid;
+        const uint32_t h = fnv_cell3(cx + dx, cy + dy, cz + dz);
+        if (h != 0u) {                                            /* a hash of 0 is never searched (kernel.cu:727) */
+            for (uint32_t s = cell_slot(h, mask);; s = (s + 1u) & mask) {
+                const uint32_t k = tab[3u * s];
+                if (k == h) {
+                    first = tab[3u * s + 1u];
+                    const uint32_t end = tab[3u * s + 2u];
+                    len = end > first && end <= (uint32_t)n ? end - first : 0u;
+                    break;
+                }
+                if (k == 0u) break;
             }
-            my_lo = lo;
         }
     }
-    for (int c = 0; c < 27; c++) {
-        if (c == 13) continue;                                   /* kernel.cu:684-689 */
-        const uint32_t h = readlane_u(my_h, c);
-        if (h == 0) continue;
-        const int lo = (int)readlane_u((uint32_t)my_lo, c);
-        for (int base = lo; base < n; base += WAVE) {
-            const int j = base + lane;
-            bool ok = false;
-            float w = 0.0f;
-            const bool in_cell = j < n && shash[j] == h;
-            if (in_cell) {
-                const float4 qo = sq[j];
-                const float qd = fabsf(8 * (1 - (q0 * qo.x + q1 * qo.y + q2 * qo.z + q3 * qo.w)));
-                ok = qd < rot_thresh_sq;
-                if (ok && !use_l1) {
-                    const float ex = tx - st[3 * j], ey = ty - st[3 * j + 1], ez = tz - st[3 * j + 2];
-                    ok = pm_sqrtf(ex * ex + ey * ey + ez * ez) < d_dist;
-                }
-                w = sw[j];
+    uint32_t incl = len;                                          /* running sums over the 27 lanes */
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += up;
+    }
+    const uint32_t excl = incl - len, total = readlane_u(incl, 26);
+    uint32_t c0 = 0;                                              /* scalar: the cell that holds list position `base` */
+    for (uint32_t base = 0; base < total; base += WAVE) {
+        const uint32_t f = base + (uint32_t)lane;
+        while (readlane_u(incl, (int)c0) <= base) c0++;           /* base < total = incl[26]: stops at 26 at the latest */
+        uint32_t cf, ce;
+        if (base + WAVE <= readlane_u(incl, (int)c0)) {           /* the 64 positions lie in one cell: the usual case in a dense cluster */
+            cf = readlane_u(first, (int)c0);
+            ce = readlane_u(excl, (int)c0);
+        } else {
+            uint32_t c = 0;                                       /* the cell of list position f: running sum <= f */
+#pragma unroll
+            for (uint32_t s2 = 16; s2 > 0; s2 >>= 1) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c + s2 - 1u) << 2), (int)incl);
+                c += v <= f ? s2 : 0u;
             }
+            c = c < 26u ? c : 26u;
+            cf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)first);
+            ce = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)excl);
+        }
+        const bool in = f < total;
+        const uint32_t j = in ? cf + (f - ce) : 0u;
+        bool ok = false;
+        float w = 0.0f;
+        if (in) {
+            const float4 qo = sq[j];
+            const float qd = fabsf(8 * (1 - (q0 * qo.x + q1 * qo.y + q2 * qo.z + q3 * qo.w)));
+            ok = qd < rot_thresh_sq;
+            if (ok && !use_l1) {
+                const float ex = tx - st[3 * j], ey = ty - st[3 * j + 1], ez = tz - st[3 * j + 2];
+                ok = pm_sqrtf(ex * ex + ey * ey + ez * ez) < d_dist;
+            }
+            w = sw[j];
+        }
+        if (whole) {
+            lane_sum += ok ? w : 0.0f;
+        } else {
             unsigned long long m = __ballot(ok);
-            while (m) {                                          /* ascending j: the reference's order */
+            while (m) {                                          /* ascending list position: the reference's order */
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 votes += readlane_f(w, b);
             }
-            if (__ballot(in_cell) != ~0ull) break;               /* the cell's run ended in this step */
         }
+    }
+    if (whole) {
+        for (int o = WAVE / 2; o > 0; o >>= 1) lane_sum += __shfl_xor(lane_sum, o, WAVE);
+        votes += lane_sum;
     }
     if (lane == 0) score[i] = votes;
 }
@@ -845,13 +913,26 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream)
     return oslamk_vote_wide(a, stream);             /* the redo list of this launch (oslam_vote_wide.hip) */
 }
 
+size_t oslamk_cluster_table_words(int n)
+{
+    uint32_t cap = 64;
+    while (cap < 2u * (uint32_t)(n > 0 ? n : 1)) cap <<= 1;
+    return 3u * (size_t)cap;
+}
+
 int oslamk_cluster_scores(int n, const float *trans, const float *quat, const int *cell, const uint32_t *shash,
                           const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
-                          float *score, void *stream)
+                          float *score, int whole_host, const unsigned long long *whole_dev, uint32_t *table, void *stream)
 {
     if (n <= 0) return 0;
+    const size_t words = oslamk_cluster_table_words(n);
+    const uint32_t mask = (uint32_t)(words / 3u) - 1u;
+    hipError_t e = hipMemsetAsync(table, 0, sizeof(uint32_t) * words, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_cell_table_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, shash, n, table, mask);
+    hipLaunchKernelGGL(k_cell_table_end, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, (hipStream_t)stream, shash, n, table, mask);
     hipLaunchKernelGGL(k_cluster_scores, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, n, trans, quat, cell,
-                       shash, reinterpret_cast<const float4 *>(sq), st, sw, d_dist, use_l1, score);
+                       table, mask, reinterpret_cast<const float4 *>(sq), st, sw, d_dist, use_l1, score, whole_host, whole_dev);
     return (int)hipGetLastError();
 }
 
