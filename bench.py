@@ -207,8 +207,10 @@ def main():
         # (64 votes) per 4.4 cycles per CU (measured); one hit voting with a chunk = 256 votes = 13 vector
         # instructions in both modes (exact mode finds its near-edge votes by search, outside the loop), at their
         # stand-alone issue costs (v_sub_u32 2.33 cycles per wave-instruction, everything else in the loop 4.2-4.3:
-        # tools/micro/valu_rate_bench.hip) on one of 1024 SIMDs; 2.4 GHz.  In the kernel's mix the instructions issue
-        # at 4.3 cycles on average (profiles/r03_pmc_sq_k_vote.txt), which is why this fraction cannot reach 1.
+        # tools/micro/valu_rate_bench.hip) on one of 1024 SIMDs; 2.4 GHz.  The kernel is bound by the issue of ALL its
+        # instructions (3.7 cycles per instruction and SIMD, scalar ones included: profiles/r03_pmc_sq_k_vote.txt,
+        # r03_ab_step_loads_and_hit_loop.txt); the loop's own 20 instructions per hit and chunk are 44 % of them,
+        # which is why this fraction cannot reach 1.
         lds_peak = 256 * 64 * 2.4e9 / 4.4
         valu_instr = 13
         valu_cycles = 47.5
@@ -257,7 +259,8 @@ def main():
                          "launches_per_step": launches / args.steps,
                          "alg_bytes_model": "4 B x model pair entries streamed (each bucket once per run of hits and slice) "
                                             "+ 16 B per (run, slice) + 8 B per hit and slice + 16 B per record",
-                         "binding": "vector issue, then LDS atomics: see roofline_valu / roofline_lds_atomic "
+                         "binding": "instruction issue, all kinds counted (3.7 cycles per instruction and SIMD with four "
+                                    "waves per SIMD), then LDS atomics: see roofline_valu / roofline_lds_atomic "
                                     "(DESIGN.md 4); the entry stream comes out of the Infinity Cache",
                          "key_kernels_ms_per_step": ms_key_kernel / args.steps,
                          "path_kernels_ms_per_step": ms_path,
