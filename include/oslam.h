@@ -61,7 +61,10 @@ typedef struct oslam_params {
                                     * measurements; the accumulators do not depend on the order) */
     unsigned scratch_gib;          /* limit of the device's hit-list pool in GiB; 0 = default (4).  A registration
                                     * whose lists need more runs in batches of reference points */
-    int reserved[3];
+    int pose_two_sorts;            /* device pose tail: order the kept cells with two stable sorts of (code, count) pairs even
+                                    * when their fields fit one packed 64-bit key (the path clouds of 2^28 points with
+                                    * 2^32 votes per cell take; identical results, tests force it) */
+    int reserved[2];
 } oslam_params;
 
 /* Counters the reference logs at debug level (model.cu:122,152,161-168;

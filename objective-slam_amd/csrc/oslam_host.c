@@ -1576,7 +1576,7 @@ static int finish_on_device(oslam_model *m, oslam_scene *s, size_t n, uint32_t g
     rc = ensure_pose_buffers(m, n);
     if (rc != OSLAM_OK) return rc;
     k = oslamk_pose_stage(m->d_out, (uint32_t)n, min_votecount, m->d_Tm16, s->d_Ts16, s->df, m->d_weights, rot, m->d_dist,
-                          m->params.use_l1_norm, m->d_pose_cells, m->d_pose_T, gmax, (uint32_t)m->c.n, (uint32_t)s->c.n, &n_kept,
+                          m->params.use_l1_norm, m->d_pose_cells, m->d_pose_T, gmax, (uint32_t)m->c.n, (uint32_t)s->c.n, m->params.pose_two_sorts, &n_kept,
                           &best, T, g_stream);
     if (k == -2) return fail(OSLAM_E_NOMEM, "host allocation failed");
     if (k != 0) return fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k));
@@ -2225,7 +2225,7 @@ int oslam_db_align(oslam_db *db, oslam_scene *s, float *T_out, oslam_stats *stat
                         kk = oslamk_pose_finish_async(n_sel, ms[k]->d_pose_cells, ms[k]->d_Tm16, s->d_Ts16, s->df, ms[k]->d_weights,
                                                       ms[k]->d_dist, ms[k]->params.use_l1_norm, ms[k]->d_pose_cells,
                                                       ms[k]->d_pose_T, cnt[k].gmax, (uint32_t)ms[k]->c.n, (uint32_t)s->c.n,
-                                                      (uint32_t)k, g_stream);
+                                                      ms[k]->params.pose_two_sorts, (uint32_t)k, g_stream);
                     }
                 if (kk == 0) kk = (int)hipStreamSynchronize((hipStream_t)g_stream);
                 if (kk != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)kk)); break; }

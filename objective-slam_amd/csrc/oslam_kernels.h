@@ -258,9 +258,9 @@ size_t oslamk_cluster_table_words(int n);
 int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, float min_votecount, const float *d_Tm16,
                       const float *d_Ts16, uint32_t df, const float *d_weights, const float *h_rotx_cs, float d_dist,
                       int use_l1, oslamk_cell *d_cells_out, float *d_poses, uint32_t gmax, uint32_t model_points,
-                      uint32_t scene_points, uint32_t *n_out, uint32_t *best_out, float T_best[16], void *stream);
+                      uint32_t scene_points, int two_sorts, uint32_t *n_out, uint32_t *best_out, float T_best[16], void *stream);
 /* gmax (the largest count among the records), model_points and scene_points bound the fields of a record: with few
- * enough bits the cells are ordered by one sort of packed keys */
+ * enough bits the cells are ordered by one sort of packed keys (two_sorts != 0: never) */
 
 /* The same tail in pieces, for several models in flight on one stream (a database frame): reserve once for the largest
  * record count and the number of models, enqueue every model's selection, wait, read the counts, enqueue every model's
@@ -271,7 +271,8 @@ int oslamk_pose_select_async(const oslamk_cell *d_in, uint32_t n_in, float min_v
 uint32_t oslamk_pose_selected(uint32_t slot);
 int oslamk_pose_finish_async(uint32_t n, const oslamk_cell *d_sel, const float *d_Tm16, const float *d_Ts16, uint32_t df,
                              const float *d_weights, float d_dist, int use_l1, oslamk_cell *d_cells_out, float *d_poses,
-                             uint32_t gmax, uint32_t model_points, uint32_t scene_points, uint32_t slot, void *stream);
+                             uint32_t gmax, uint32_t model_points, uint32_t scene_points, int two_sorts, uint32_t slot,
+                             void *stream);
 void oslamk_pose_result(uint32_t slot, uint32_t *best_out, float T_best[16]);
 
 /* records with count > min_votecount, compacted into d_out (capacity n_in); *n_out on the host */

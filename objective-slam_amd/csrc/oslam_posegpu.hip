@@ -364,7 +364,7 @@ static uint32_t bits_for(uint64_t max_value)
 extern "C" int oslamk_pose_finish_async(uint32_t n, const oslamk_cell *d_sel, const float *d_Tm16, const float *d_Ts16,
                                         uint32_t df, const float *d_weights, float d_dist, int use_l1,
                                         oslamk_cell *d_cells_out, float *d_poses, uint32_t gmax, uint32_t model_points,
-                                        uint32_t scene_points, uint32_t slot, void *stream_)
+                                        uint32_t scene_points, int two_sorts, uint32_t slot, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     pose_pool *p = cur_pool();
@@ -393,7 +393,7 @@ extern "C" int oslamk_pose_finish_async(uint32_t n, const oslamk_cell *d_sel, co
         pose_pack pk = {0, 0, gmax};
         {
             const uint32_t lb = 6 + bits_for(model_points ? model_points - 1u : 0u), sb = bits_for(scene_points ? scene_points - 1u : 0u);
-            if (lb <= 32 && lb + sb + bits_for(gmax) <= 64) { pk.lb = lb; pk.cb = lb + sb; }
+            if (!two_sorts && lb <= 32 && lb + sb + bits_for(gmax) <= 64) { pk.lb = lb; pk.cb = lb + sb; }
         }
         hipLaunchKernelGGL(k_pose_split, dim3(blocks), dim3(256), 0, stream, d_sel, n, codeA, cntA, whole, pk);
         if (pk.cb) {
@@ -465,7 +465,7 @@ extern "C" void oslamk_pose_release(void)
 extern "C" int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, float min_votecount, const float *d_Tm16,
                                  const float *d_Ts16, uint32_t df, const float *d_weights, const float *h_rotx_cs,
                                  float d_dist, int use_l1, oslamk_cell *d_cells_out, float *d_poses, uint32_t gmax,
-                                 uint32_t model_points, uint32_t scene_points, uint32_t *n_out,
+                                 uint32_t model_points, uint32_t scene_points, int two_sorts, uint32_t *n_out,
                                  uint32_t *best_out, float T_best[16], void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -483,7 +483,7 @@ extern "C" int oslamk_pose_stage(const oslamk_cell *d_cells_in, uint32_t n_in, f
     *n_out = n;
     if (n < 2) return 0;                               /* the caller's host path handles 0 and 1 cells */
     rc = oslamk_pose_finish_async(n, d_cells_out, d_Tm16, d_Ts16, df, d_weights, d_dist, use_l1, d_cells_out, d_poses, gmax,
-                                  model_points, scene_points, 0, stream_);
+                                  model_points, scene_points, two_sorts, 0, stream_);
     if (rc != 0) return rc;
     PCHK(hipStreamSynchronize(stream));
     oslamk_pose_result(0, best_out, T_best);

@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("cpu_clustering", C.c_int), ("use_l1_norm", C.c_int), ("use_averaged_clusters", C.c_int),
                 ("dev", C.c_int), ("vote_mode", C.c_int), ("shard_rank", C.c_int), ("shard_world", C.c_int),
                 ("max_cells", C.c_uint), ("pose_gpu_min", C.c_uint), ("no_bucket_spread", C.c_int),
-                ("scratch_gib", C.c_uint), ("reserved", C.c_int * 3)]
+                ("scratch_gib", C.c_uint), ("pose_two_sorts", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class Stats(C.Structure):

@@ -590,6 +590,23 @@ def pose_tail_on_device(monkeypatch):
     monkeypatch.setitem(importlib.import_module("objective-slam_amd").ppf.DEFAULT_OVERRIDES, "pose_gpu_min", 2)
 
 
+def test_device_pose_tail_two_sorts_equals_oracle(ppf, oracle, built_lib, case_small, case_two_slices, pose_tail_on_device, monkeypatch):
+    """The order of the kept cells (count descending, code ascending) normally comes from one sort of packed keys; clouds
+    whose fields do not fit 64 bits take two stable sorts of (code, count) pairs instead -- forced here: same cells in the
+    same order, same poses, same winner."""
+    import importlib
+    monkeypatch.setitem(importlib.import_module("objective-slam_amd").ppf.DEFAULT_OVERRIDES, "pose_two_sorts", 1)
+    for c, df, flags in ((case_small, 1, {}), (case_two_slices, 10, {}), (case_small, 3, dict(use_l1_norm=True))):
+        _align_and_compare(ppf, oracle, c, df=df, **flags)
+        sc = ppf.Scene(c["sp"], c["sn"], d_dist=c["d"], ref_point_downsample_factor=df)
+        mo = ppf.Model(c["mp"], c["mn"], d_dist=c["d"], **flags)
+        mo.ppf_lookup(sc)
+        ocells, _ = oracle.votes_fused(c["mp"], c["mn"], c["sp"], c["sn"], df, c["d"], 0.4)
+        cells, poses = mo.last_cells()
+        assert cells_equal(cells, ocells)
+        assert np.array_equal(poses, oracle.trans_calc2(ocells, c["mp"], c["mn"], c["sp"], c["sn"]))
+
+
 def test_device_pose_tail_equals_oracle(ppf, oracle, built_lib, case_small, case_two_slices, synth, pose_tail_on_device):
     """Filter, order, K5..K9 and the winner on the GPU: kept cells (in order), every pose matrix and the
     returned pose equal the oracle's, as the host tail's do; also with the l1 flag, with point
