@@ -135,12 +135,12 @@ extern "C" int oslamk_depth_to_cloud(const void *d_img, int is_u16, int w, int h
     uint32_t last[2] = {0, 0};
     *n_out = 0;
     if (n == 0) return 0;
-    DCHK(hipMalloc((void **)&d_tmp6, sizeof(float) * 6 * n));
-    DCHK(hipMalloc((void **)&d_u, sizeof(uint32_t) * 2 * n));
+    DCHK((hipError_t)oslam_dev_alloc((void **)&d_tmp6, sizeof(float) * 6 * n));
+    DCHK((hipError_t)oslam_dev_alloc((void **)&d_u, sizeof(uint32_t) * 2 * n));
     hipLaunchKernelGGL(k_depth_points, dim3((w + 31) / 32, (h + 7) / 8), dim3(256), 0, stream, d_img, is_u16, w, h, c,
                        d_tmp6, d_u);
     DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, d_u, d_u + n, 0u, n, rocprim::plus<uint32_t>(), stream));
-    DCHK(hipMalloc(&d_scan, scan_bytes ? scan_bytes : 16));
+    DCHK((hipError_t)oslam_dev_alloc(&d_scan, scan_bytes ? scan_bytes : 16));
     DCHK(rocprim::exclusive_scan(d_scan, scan_bytes, d_u, d_u + n, 0u, n, rocprim::plus<uint32_t>(), stream));
     hipLaunchKernelGGL(k_depth_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_tmp6, d_u, d_u + n, n,
                        d_out6);
@@ -150,8 +150,8 @@ extern "C" int oslamk_depth_to_cloud(const void *d_img, int is_u16, int w, int h
     DCHK(hipGetLastError());
     *n_out = last[0] + last[1];
 done:
-    if (d_tmp6) (void)hipFree(d_tmp6);
-    if (d_u) (void)hipFree(d_u);
-    if (d_scan) (void)hipFree(d_scan);
+    oslam_dev_free(d_tmp6);
+    oslam_dev_free(d_u);
+    oslam_dev_free(d_scan);
     return rc;
 }

@@ -184,11 +184,94 @@ static int pick_device(int dev_req, int *dev_out)
     return OSLAM_OK;
 }
 
+/* ---- kept device blocks of the scene path (oslam_kernels.h) ---- */
+#define DEVCACHE_SLOTS 64
+#define DEVCACHE_MAX_BLOCK ((size_t)1 << 30)        /* larger blocks go straight back to the driver */
+typedef struct {
+    void *p;
+    size_t bytes;
+    int dev, used;
+} devblock;
+static devblock g_devcache[DEVCACHE_SLOTS];
+static pthread_mutex_t g_devcache_mu = PTHREAD_MUTEX_INITIALIZER;
+
+int oslam_dev_alloc(void **out, size_t bytes)
+{
+    int dev = 0, i, best = -1, spare = -1;
+    hipError_t e;
+    size_t want;
+    *out = NULL;
+    if (bytes == 0) bytes = 16;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+    pthread_mutex_lock(&g_devcache_mu);
+    for (i = 0; i < DEVCACHE_SLOTS; i++) {
+        devblock *b = &g_devcache[i];
+        if (!b->p) { if (spare < 0) spare = i; continue; }
+        if (b->used || b->dev != dev || b->bytes < bytes || b->bytes > 2 * bytes + 65536) continue;
+        if (best < 0 || b->bytes < g_devcache[best].bytes) best = i;
+    }
+    if (best >= 0) {
+        g_devcache[best].used = 1;
+        *out = g_devcache[best].p;
+        pthread_mutex_unlock(&g_devcache_mu);
+        return 0;
+    }
+    /* a frame's clouds differ by a few per cent from the last one's: head room lets the next frame reuse the block */
+    want = bytes <= DEVCACHE_MAX_BLOCK ? bytes + bytes / 8 + 256 : bytes;
+    e = hipMalloc(out, want);
+    if (e != hipSuccess) {              /* out of memory with blocks kept: give them back and try once more */
+        (void)hipGetLastError();
+        for (i = 0; i < DEVCACHE_SLOTS; i++)
+            if (g_devcache[i].p && !g_devcache[i].used && g_devcache[i].dev == dev) {
+                (void)hipFree(g_devcache[i].p);
+                memset(&g_devcache[i], 0, sizeof g_devcache[i]);
+                if (spare < 0) spare = i;
+            }
+        want = bytes;
+        e = hipMalloc(out, want);
+    }
+    if (e == hipSuccess && spare >= 0 && want <= DEVCACHE_MAX_BLOCK) {
+        g_devcache[spare].p = *out;
+        g_devcache[spare].bytes = want;
+        g_devcache[spare].dev = dev;
+        g_devcache[spare].used = 1;
+    }
+    pthread_mutex_unlock(&g_devcache_mu);
+    return (int)e;
+}
+
+void oslam_dev_free(void *p)
+{
+    int i;
+    if (!p) return;
+    pthread_mutex_lock(&g_devcache_mu);
+    for (i = 0; i < DEVCACHE_SLOTS; i++)
+        if (g_devcache[i].p == p) {
+            g_devcache[i].used = 0;
+            pthread_mutex_unlock(&g_devcache_mu);
+            return;
+        }
+    pthread_mutex_unlock(&g_devcache_mu);
+    (void)hipFree(p);                   /* not one of the kept blocks (table full, or too large) */
+}
+
+void oslam_dev_cache_release(int dev)
+{
+    int i;
+    pthread_mutex_lock(&g_devcache_mu);
+    for (i = 0; i < DEVCACHE_SLOTS; i++)
+        if (g_devcache[i].p && !g_devcache[i].used && g_devcache[i].dev == dev) {
+            (void)hipFree(g_devcache[i].p);
+            memset(&g_devcache[i], 0, sizeof g_devcache[i]);
+        }
+    pthread_mutex_unlock(&g_devcache_mu);
+}
+
 static void cloud_free(cloud_buf *c)
 {
     free(c->h_xyz);
     free(c->h_nrm);
-    if (c->d_soa) (void)hipFree(c->d_soa);
+    if (c->d_soa) oslam_dev_free(c->d_soa);
     memset(c, 0, sizeof *c);
 }
 
@@ -215,7 +298,7 @@ static int cloud_upload(cloud_buf *c, const float *xyz, const float *nrm, size_t
             soa[(size_t)(3 + a) * n + i] = q[a];
         }
     }
-    HIPCHK(hipMalloc((void **)&c->d_soa, sizeof(float) * 6 * n));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&c->d_soa, sizeof(float) * 6 * n));
     HIPCHK(hipMemcpy(c->d_soa, soa, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
     c->k.px = c->d_soa;
     c->k.py = c->d_soa + n;
@@ -244,7 +327,7 @@ static int cloud_from_device6(cloud_buf *c, const float *d_aos6, size_t n)
     c->h_nrm = (float *)malloc(sizeof(float) * 3 * n);
     h6 = (float *)malloc(sizeof(float) * 6 * n);
     if (!c->h_xyz || !c->h_nrm || !h6) { rc = fail(OSLAM_E_NOMEM, "host allocation failed"); goto done; }
-    HIPCHK(hipMalloc((void **)&c->d_soa, sizeof(float) * 6 * n));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&c->d_soa, sizeof(float) * 6 * n));
     KCHK(oslamk_aos6_to_soa(d_aos6, n, c->d_soa, g_stream));
     HIPCHK(hipMemcpyAsync(h6, d_aos6, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, (hipStream_t)g_stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)g_stream));
@@ -283,7 +366,7 @@ int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride
     if (rc != OSLAM_OK) return rc;
     rc = cloud_upload(&c, xyz, nrm, n, stride_bytes);
     if (rc != OSLAM_OK) return rc;
-    HIPCHK(hipMalloc((void **)&d_out, sizeof(float) * 6 * n));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&d_out, sizeof(float) * 6 * n));
     k = oslamk_voxel_grid(c.k, leaf, d_out, &nv, g_stream);
     if (k == -1) { rc = fail(OSLAM_E_LIMIT, "leaf size too small for the cloud extent (voxel count overflows int32)"); goto done; }
     if (k != 0) { rc = fail(OSLAM_E_DEVICE, hipGetErrorString((hipError_t)k)); goto done; }
@@ -298,7 +381,7 @@ int oslam_voxel_grid(const float *xyz, const float *nrm, size_t n, size_t stride
     *n_out = nv;
 done:
     free(h_out);
-    if (d_out) (void)hipFree(d_out);
+    oslam_dev_free(d_out);
     cloud_free(&c);
     return rc;
 }
@@ -321,8 +404,8 @@ int oslam_depth_to_cloud(const void *depth, int depth_is_u16, int width, int hei
     px_bytes = depth_is_u16 ? 2 : 4;
     rc = pick_device(dev, &devsel);
     if (rc != OSLAM_OK) return rc;
-    HIPCHK(hipMalloc(&d_img, n_pix * px_bytes));
-    HIPCHK(hipMalloc((void **)&d_out, sizeof(float) * 6 * n_pix));
+    HIPCHK((hipError_t)oslam_dev_alloc(&d_img, n_pix * px_bytes));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&d_out, sizeof(float) * 6 * n_pix));
     HIPCHK(hipMemcpyAsync(d_img, depth, n_pix * px_bytes, hipMemcpyHostToDevice, (hipStream_t)g_stream));
     k = oslamk_depth_to_cloud(d_img, depth_is_u16 != 0, width, height, cam->fx, cam->fy, cam->cx, cam->cy, cam->depth_scale,
                               cam->z_min, cam->z_max, cam->max_jump, d_out, &np, g_stream);
@@ -338,8 +421,8 @@ int oslam_depth_to_cloud(const void *depth, int depth_is_u16, int width, int hei
     *n_out = np;
 done:
     free(h_out);
-    if (d_img) (void)hipFree(d_img);
-    if (d_out) (void)hipFree(d_out);
+    oslam_dev_free(d_img);
+    oslam_dev_free(d_out);
     return rc;
 }
 
@@ -859,9 +942,9 @@ void oslam_scene_destroy(oslam_scene *s)
     (void)hipSetDevice(s->dev);
     cloud_free(&s->c);
     free(s->h_ref_idx);
-    if (s->d_ref_idx) (void)hipFree(s->d_ref_idx);
-    if (s->d_tsg) (void)hipFree(s->d_tsg);
-    if (s->d_Ts16) (void)hipFree(s->d_Ts16);
+    oslam_dev_free(s->d_ref_idx);
+    oslam_dev_free(s->d_tsg);
+    oslam_dev_free(s->d_Ts16);
     free(s);
 }
 
@@ -903,8 +986,8 @@ static int scene_create_any(const float *xyz, const float *nrm, size_t stride_by
         for (t = (size_t)s->rank; t < n_all; t += (size_t)s->world) s->h_ref_idx[k++] = (uint32_t)(t * df);
     }
     oslam_T_g_rows(s->c.h_xyz, s->c.h_nrm, s->h_ref_idx, (size_t)s->n_ref, h_tsg);
-    HIPCHK(hipMalloc((void **)&s->d_ref_idx, sizeof(uint32_t) * (s->n_ref ? s->n_ref : 1)));
-    HIPCHK(hipMalloc((void **)&s->d_tsg, sizeof(float) * 8 * (s->n_ref ? s->n_ref : 1)));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&s->d_ref_idx, sizeof(uint32_t) * (s->n_ref ? s->n_ref : 1)));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&s->d_tsg, sizeof(float) * 8 * (s->n_ref ? s->n_ref : 1)));
     if (s->n_ref) {
         HIPCHK(hipMemcpy(s->d_ref_idx, s->h_ref_idx, sizeof(uint32_t) * s->n_ref, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(s->d_tsg, h_tsg, sizeof(float) * 8 * s->n_ref, hipMemcpyHostToDevice));
@@ -948,8 +1031,8 @@ int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int h
     px_bytes = depth_is_u16 ? 2 : 4;
     rc = pick_device(p.dev, &devsel);
     if (rc != OSLAM_OK) return rc;
-    HIPCHK(hipMalloc(&d_img, n_pix * px_bytes));
-    HIPCHK(hipMalloc((void **)&d_pts6, sizeof(float) * 6 * n_pix));
+    HIPCHK((hipError_t)oslam_dev_alloc(&d_img, n_pix * px_bytes));
+    HIPCHK((hipError_t)oslam_dev_alloc((void **)&d_pts6, sizeof(float) * 6 * n_pix));
     HIPCHK(hipMemcpyAsync(d_img, depth, n_pix * px_bytes, hipMemcpyHostToDevice, (hipStream_t)g_stream));
     k = oslamk_depth_to_cloud(d_img, depth_is_u16 != 0, width, height, cam->fx, cam->fy, cam->cx, cam->cy, cam->depth_scale,
                               cam->z_min, cam->z_max, cam->max_jump, d_pts6, &np, g_stream);
@@ -958,8 +1041,8 @@ int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int h
     n_final = np;
     if (leaf > 0.0f && np > 0) {
         oslamk_cloud c;
-        HIPCHK(hipMalloc((void **)&d_soa, sizeof(float) * 6 * (size_t)np));
-        HIPCHK(hipMalloc((void **)&d_vox6, sizeof(float) * 6 * (size_t)np));
+        HIPCHK((hipError_t)oslam_dev_alloc((void **)&d_soa, sizeof(float) * 6 * (size_t)np));
+        HIPCHK((hipError_t)oslam_dev_alloc((void **)&d_vox6, sizeof(float) * 6 * (size_t)np));
         KCHK(oslamk_aos6_to_soa(d_pts6, np, d_soa, g_stream));
         c.px = d_soa; c.py = d_soa + np; c.pz = d_soa + 2 * (size_t)np;
         c.nx = d_soa + 3 * (size_t)np; c.ny = d_soa + 4 * (size_t)np; c.nz = d_soa + 5 * (size_t)np;
@@ -975,10 +1058,10 @@ int oslam_scene_from_depth(const void *depth, int depth_is_u16, int width, int h
     rc = scene_create_any(NULL, NULL, 0, d_final, n_final, d_dist, df, &p, out);
     if (rc == OSLAM_OK && n_points_out) *n_points_out = n_final;
 done:
-    if (d_img) (void)hipFree(d_img);
-    if (d_pts6) (void)hipFree(d_pts6);
-    if (d_soa) (void)hipFree(d_soa);
-    if (d_vox6) (void)hipFree(d_vox6);
+    oslam_dev_free(d_img);
+    oslam_dev_free(d_pts6);
+    oslam_dev_free(d_soa);
+    oslam_dev_free(d_vox6);
     return rc;
 }
 
@@ -1055,6 +1138,7 @@ int oslam_release_scratch(int dev)
         if (p->have_events)
             for (i = 0; i < 4 + 3 * MAX_BATCH_EVENTS; i++) (void)hipEventDestroy(p->ev[i]);
     }
+    if (hipSetDevice(dev) == hipSuccess) oslam_dev_cache_release(dev);   /* the kept blocks of the scene path */
     free(p->h_counts);
     p->buf = NULL;
     p->bytes = 0;
@@ -1521,7 +1605,7 @@ static int pose_tables(oslam_model *m, oslam_scene *s)
         h = (float *)malloc(sizeof(float) * 16 * n_all);
         if (!h) return fail(OSLAM_E_NOMEM, "host allocation failed");
         oslam_T_g_full(s->c.h_xyz, s->c.h_nrm, 0, s->df, n_all, h);
-        HIPCHK(hipMalloc((void **)&d_S, sizeof(float) * 16 * n_all));
+        HIPCHK((hipError_t)oslam_dev_alloc((void **)&d_S, sizeof(float) * 16 * n_all));
         HIPCHK(hipMemcpy(d_S, h, sizeof(float) * 16 * n_all, hipMemcpyHostToDevice));
         s->d_Ts16 = d_S;
         d_S = NULL;
@@ -1530,7 +1614,7 @@ done:
     free(h);
     if (d_T) (void)hipFree(d_T);
     if (d_w) (void)hipFree(d_w);
-    if (d_S) (void)hipFree(d_S);
+    oslam_dev_free(d_S);
     return rc;
 }
 

@@ -238,6 +238,15 @@ int oslamk_depth_to_cloud(const void *d_img, int is_u16, int w, int h, float fx,
                           float scale, float z_min, float z_max, float max_jump, float *d_out6, uint32_t *n_out,
                           void *stream);
 
+/* Device memory of the per-frame scene path (depth image, voxel grid, scene arrays).  hipFree waits for the device --
+ * 0.2 ms a time, and a depth frame freed a dozen blocks -- so freed blocks are kept (per device, up to a limit) and
+ * handed out again to requests they fit.  Everything on this path runs on one stream and is waited for before its
+ * buffers are given back, so a block is never reused under a kernel.  oslam_dev_alloc returns a hipError_t as int;
+ * oslam_release_scratch gives the kept blocks of a device back to the driver. */
+int oslam_dev_alloc(void **p, size_t bytes);
+void oslam_dev_free(void *p);
+void oslam_dev_cache_release(int dev);
+
 /* device [n][6] (x y z nx ny nz) -> device structure of arrays [6][n] */
 int oslamk_aos6_to_soa(const float *d_in6, size_t n, float *d_soa, void *stream);
 

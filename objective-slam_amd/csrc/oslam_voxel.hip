@@ -117,8 +117,8 @@ extern "C" int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32
     uint32_t last[2] = {0, 0};
     *n_out = 0;
     if (n <= 0) return 0;
-    VCHK(hipMalloc((void **)&d_lo, sizeof(float) * 3 * nblk));
-    VCHK(hipMalloc((void **)&d_hi, sizeof(float) * 3 * nblk));
+    VCHK((hipError_t)oslam_dev_alloc((void **)&d_lo, sizeof(float) * 3 * nblk));
+    VCHK((hipError_t)oslam_dev_alloc((void **)&d_hi, sizeof(float) * 3 * nblk));
     hipLaunchKernelGGL(k_vox_bbox, dim3(nblk), dim3(256), 0, stream, c, d_lo, d_hi);
     h = (float *)malloc(sizeof(float) * 6 * nblk);
     VCHK(hipMemcpyAsync(h, d_lo, sizeof(float) * 3 * nblk, hipMemcpyDeviceToHost, stream));
@@ -138,7 +138,7 @@ extern "C" int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32
     }
     if ((long long)db[0] * db[1] > 0x7fffffffLL || (long long)db[0] * db[1] * db[2] > 0x7fffffffLL) { rc = -1; goto done; }
 
-    VCHK(hipMalloc((void **)&d_u, sizeof(uint32_t) * 6 * (size_t)n));
+    VCHK((hipError_t)oslam_dev_alloc((void **)&d_u, sizeof(uint32_t) * 6 * (size_t)n));
     {
         uint32_t *k_in = d_u, *v_in = d_u + n, *k_out = d_u + 2 * (size_t)n, *v_out = d_u + 3 * (size_t)n;
         uint32_t *flags = d_u + 4 * (size_t)n, *ord = d_u + 5 * (size_t)n;
@@ -147,7 +147,7 @@ extern "C" int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32
         VCHK(rocprim::radix_sort_pairs(nullptr, tmp_sort, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, stream));
         VCHK(rocprim::exclusive_scan(nullptr, tmp_scan, flags, ord, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
         tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
-        VCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+        VCHK((hipError_t)oslam_dev_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
         VCHK(rocprim::radix_sort_pairs(d_tmp, tmp_sort, k_in, k_out, v_in, v_out, (size_t)n, 0, 32, stream));
         hipLaunchKernelGGL(k_vox_heads, dim3((n + 255) / 256), dim3(256), 0, stream, k_out, n, flags);
         VCHK(rocprim::exclusive_scan(d_tmp, tmp_scan, flags, ord, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
@@ -160,9 +160,9 @@ extern "C" int oslamk_voxel_grid(oslamk_cloud c, float leaf, float *out6, uint32
     }
 done:
     free(h);
-    if (d_lo) (void)hipFree(d_lo);
-    if (d_hi) (void)hipFree(d_hi);
-    if (d_u) (void)hipFree(d_u);
-    if (d_tmp) (void)hipFree(d_tmp);
+    oslam_dev_free(d_lo);
+    oslam_dev_free(d_hi);
+    oslam_dev_free(d_u);
+    oslam_dev_free(d_tmp);
     return rc;
 }
