@@ -735,47 +735,64 @@ __global__ __launch_bounds__(64) void k_cluster_scores(int n, const float *trans
         if (lane >= o) incl += up;
     }
     const uint32_t excl = incl - len, total = readlane_u(incl, 26);
-    uint32_t c0 = 0;                                              /* scalar: the cell that holds list position `base` */
-    for (uint32_t base = 0; base < total; base += WAVE) {
-        const uint32_t f = base + (uint32_t)lane;
-        while (readlane_u(incl, (int)c0) <= base) c0++;           /* base < total = incl[26]: stops at 26 at the latest */
-        uint32_t cf, ce;
-        if (base + WAVE <= readlane_u(incl, (int)c0)) {           /* the 64 positions lie in one cell: the usual case in a dense cluster */
-            cf = readlane_u(first, (int)c0);
-            ce = readlane_u(excl, (int)c0);
-        } else {
-            uint32_t c = 0;                                       /* the cell of list position f: running sum <= f */
+    uint32_t c0 = 0;                                              /* scalar: the cell that holds the list position being placed */
+    /* Four times 64 list positions per round, all their loads issued before the first test: a pose in a dense cluster
+     * walks thousands of candidates, and with one load round trip per 64 of them the kernel's time was the longest such
+     * walk (1.4 ms per model on the 4-model depth stream), not its work. */
+    for (uint32_t base = 0; base < total; base += 4u * WAVE) {
+        uint32_t j[4];
+        bool in[4];
 #pragma unroll
-            for (uint32_t s2 = 16; s2 > 0; s2 >>= 1) {
-                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c + s2 - 1u) << 2), (int)incl);
-                c += v <= f ? s2 : 0u;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = base + (uint32_t)u * WAVE, f = b + (uint32_t)lane;
+            in[u] = f < total;
+            j[u] = 0;
+            if (b >= total) continue;                             /* wave-uniform */
+            while (readlane_u(incl, (int)c0) <= b) c0++;          /* b < total = incl[26]: stops at 26 at the latest */
+            uint32_t cf, ce;
+            if (b + WAVE <= readlane_u(incl, (int)c0)) {          /* the 64 positions lie in one cell: the usual case in a dense cluster */
+                cf = readlane_u(first, (int)c0);
+                ce = readlane_u(excl, (int)c0);
+            } else {
+                uint32_t c = 0;                                   /* the cell of list position f: running sum <= f */
+#pragma unroll
+                for (uint32_t s2 = 16; s2 > 0; s2 >>= 1) {
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c + s2 - 1u) << 2), (int)incl);
+                    c += v <= f ? s2 : 0u;
+                }
+                c = c < 26u ? c : 26u;
+                cf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)first);
+                ce = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)excl);
             }
-            c = c < 26u ? c : 26u;
-            cf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)first);
-            ce = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)excl);
+            j[u] = in[u] ? cf + (f - ce) : 0u;
         }
-        const bool in = f < total;
-        const uint32_t j = in ? cf + (f - ce) : 0u;
-        bool ok = false;
-        float w = 0.0f;
-        if (in) {
-            const float4 qo = sq[j];
-            const float qd = fabsf(8 * (1 - (q0 * qo.x + q1 * qo.y + q2 * qo.z + q3 * qo.w)));
-            ok = qd < rot_thresh_sq;
+        float4 qo[4];
+        float ex[4], ey[4], ez[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                             /* position 0 for the lanes past the end: loaded, not used */
+            qo[u] = sq[j[u]];
+            ex[u] = st[3 * j[u]];
+            ey[u] = st[3 * j[u] + 1];
+            ez[u] = st[3 * j[u] + 2];
+            w[u] = sw[j[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float qd = fabsf(8 * (1 - (q0 * qo[u].x + q1 * qo[u].y + q2 * qo[u].z + q3 * qo[u].w)));
+            bool ok = in[u] && qd < rot_thresh_sq;
             if (ok && !use_l1) {
-                const float ex = tx - st[3 * j], ey = ty - st[3 * j + 1], ez = tz - st[3 * j + 2];
-                ok = pm_sqrtf(ex * ex + ey * ey + ez * ez) < d_dist;
+                const float dx = tx - ex[u], dy = ty - ey[u], dz = tz - ez[u];
+                ok = pm_sqrtf(dx * dx + dy * dy + dz * dz) < d_dist;
             }
-            w = sw[j];
-        }
-        if (whole) {
-            lane_sum += ok ? w : 0.0f;
-        } else {
-            unsigned long long m = __ballot(ok);
-            while (m) {                                          /* ascending list position: the reference's order */
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                votes += readlane_f(w, b);
+            if (whole) {
+                lane_sum += ok ? w[u] : 0.0f;
+            } else {
+                unsigned long long m = __ballot(ok);
+                while (m) {                                      /* ascending list position: the reference's order */
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    votes += readlane_f(w[u], b);
+                }
             }
         }
     }
