@@ -1098,6 +1098,8 @@ typedef struct {
     char *d_cluster;                   /* workspace of cluster_scores_on_device */
     size_t cluster_bytes;
     uint32_t *d_redo;                  /* vote workgroups of a batch whose 16-bit counters overflowed */
+    oslamk_vote_args *d_vargs, *h_vargs;   /* a group's vote arguments, one per member (h: pinned), for the one-grid launch */
+    size_t vargs_cap;
     size_t redo_cap;
 } scratch_pool;
 static scratch_pool g_pool[MAX_DEVICES];
@@ -1128,12 +1130,14 @@ int oslam_release_scratch(int dev)
     scratch_pool *p = pool_lock(dev);
     int i;
     if (!p) return fail(OSLAM_E_INVALID, "device ordinal out of range");
-    if (p->buf || p->d_counts || p->have_events || p->d_cluster || p->d_redo) {
+    if (p->buf || p->d_counts || p->have_events || p->d_cluster || p->d_redo || p->d_vargs || p->h_vargs) {
         if (hipSetDevice(dev) != hipSuccess) { pool_unlock(p); return fail(OSLAM_E_DEVICE, "hipSetDevice failed"); }
         if (p->buf) (void)hipFree(p->buf);
         if (p->d_counts) (void)hipFree(p->d_counts);
         if (p->d_cluster) (void)hipFree(p->d_cluster);
         if (p->d_redo) (void)hipFree(p->d_redo);
+        if (p->d_vargs) (void)hipFree(p->d_vargs);
+        if (p->h_vargs) (void)hipHostFree(p->h_vargs);
         oslamk_pose_release();
         if (p->have_events)
             for (i = 0; i < 4 + 3 * MAX_BATCH_EVENTS; i++) (void)hipEventDestroy(p->ev[i]);
@@ -1150,6 +1154,9 @@ int oslam_release_scratch(int dev)
     p->cluster_bytes = 0;
     p->d_redo = NULL;
     p->redo_cap = 0;
+    p->d_vargs = NULL;
+    p->h_vargs = NULL;
+    p->vargs_cap = 0;
     pool_unlock(p);
     return OSLAM_OK;
 }
@@ -1257,7 +1264,8 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
     hipStream_t st = (hipStream_t)g_stream;
     hipEvent_t *ev;
     const size_t limit_slots = scratch_limit(ms[0]) / SLOT_BYTES;
-    size_t cap, max_batch_slots = 0;
+    size_t cap, max_batch_slots = 0, redo_stride = 0;
+    int one_grid = 0;
     uint32_t *h_keep, *h_off, *d_keep, *d_hitc, *d_runc, *d_off;
     float k0 = 0.0f;
     rc = pool_reserve_counts(pool, (size_t)(n_ref > 0 ? n_ref : 1));
@@ -1267,6 +1275,8 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
         size_t nsl = 1, need;
         for (j = 0; j < nm; j++) if ((size_t)ms[j]->table.n_slices > nsl) nsl = (size_t)ms[j]->table.n_slices;
         need = (((size_t)(n_ref > 0 ? n_ref : 1) + 7) / 8 * 8) * nsl;
+        redo_stride = need;
+        if (nm > 1) need *= (size_t)nm;           /* a group voted in one grid: every member its own list */
         if (pool->redo_cap < need) {
             if (pool->d_redo) { (void)hipFree(pool->d_redo); pool->d_redo = NULL; pool->redo_cap = 0; }
             HIPCHK(hipMalloc((void **)&pool->d_redo, sizeof(uint32_t) * (need + need / 4)));
@@ -1333,6 +1343,30 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
         if (rc != OSLAM_OK) goto done;
         if (pos) HIPCHK(hipMemcpyAsync(d_off, h_off, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, st));
     }
+    /* A group whose frame is one batch votes in ONE grid (k_vote_group): fifty small models are fifty grids of little
+     * more than one round of workgroups otherwise, each with its own tail and its own three launches. */
+    if (nm > 1 && n_ref > 0 && !acc_dump) {
+        size_t slots;
+        size_t nsl = 1;
+        for (j = 0; j < nm; j++) if ((size_t)ms[j]->table.n_slices > nsl) nsl = (size_t)ms[j]->table.n_slices;
+        /* ... where it pays: members whose own grid is a few rounds of workgroups at most.  A member with tens of
+         * thousands of workgroups fills the chip by itself, and the kernel that takes its arguments from memory keeps
+         * more of them in registers than the one that gets them as kernel arguments (10 x 5000 points against 100k:
+         * 342 ms in one grid, 313 ms in ten). */
+        one_grid = batch_extent(h_keep, 0, n_ref, limit_slots, NULL, &slots) == n_ref &&
+                   ((size_t)n_ref + 7) / 8 * 8 * nsl <= 2048;
+        for (j = 1; j < nm && one_grid; j++)
+            if ((ms[j]->params.vote_mode == OSLAM_VOTE_FAST) != (ms[0]->params.vote_mode == OSLAM_VOTE_FAST)) one_grid = 0;
+        if (one_grid && pool->vargs_cap < (size_t)nm) {
+            const size_t want = (size_t)nm + (size_t)nm / 2 + 8;
+            if (pool->d_vargs) { (void)hipFree(pool->d_vargs); pool->d_vargs = NULL; }
+            if (pool->h_vargs) { (void)hipHostFree(pool->h_vargs); pool->h_vargs = NULL; }
+            pool->vargs_cap = 0;
+            HIPCHK(hipMalloc((void **)&pool->d_vargs, sizeof(oslamk_vote_args) * want));
+            HIPCHK(hipHostMalloc((void **)&pool->h_vargs, sizeof(oslamk_vote_args) * want, hipHostMallocDefault));
+            pool->vargs_cap = want;
+        }
+    }
     /* 3. the batches */
     {
         size_t pos = 0;
@@ -1356,15 +1390,26 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
                 const oslam_model *mj = ms[j];
                 a.table.uinfo = mj->table.uinfo;          /* its buckets, under the shared union slots */
                 a.table.n_slices = mj->table.n_slices;
+                a.table.slots = mj->table.slots;
+                a.table.cap = mj->table.cap;
                 a.ent = mj->ent;
                 a.thresh = mj->params.vote_count_threshold;
                 a.counters = mj->d_counters;
                 a.out = mj->d_out;
                 a.out_cap = mj->out_cap;
                 a.mode = (mj->params.vote_mode == OSLAM_VOTE_FAST) ? 1 : 0;
+                if (one_grid) {
+                    a.redo = pool->d_redo + (size_t)j * redo_stride;
+                    pool->h_vargs[j] = a;
+                    continue;
+                }
                 KCHK(oslamk_vote(&a, g_stream));
                 /* the redo list belongs to this launch */
                 HIPCHK(hipMemsetAsync(&mj->d_counters->redo_count, 0, sizeof(uint32_t), st));
+            }
+            if (one_grid) {
+                HIPCHK(hipMemcpyAsync(pool->d_vargs, pool->h_vargs, sizeof(oslamk_vote_args) * (size_t)nm, hipMemcpyHostToDevice, st));
+                KCHK(oslamk_vote_group(pool->d_vargs, pool->h_vargs, nm, g_stream));
             }
             if (timed) HIPCHK(hipEventRecord(ev[4 + 3 * nb + 2], st));
             if (launches) *launches += 1;

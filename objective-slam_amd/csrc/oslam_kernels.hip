@@ -637,6 +637,18 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote(oslamk_vote_args a)
 {
     vote_body<MODE, 0>(a, blockIdx.x);
 }
+/* The votes of all the members of a database group in ONE grid: member j = blockIdx / workgroups per member, its
+ * arguments from an array in device memory (copied to scalar registers as a kernel argument would be).  Every member
+ * votes the same batch of reference points; a member with fewer slices than the widest leaves its surplus
+ * workgroups at once (vote_body's own test of the reference point).  Fifty models on a depth frame are fifty grids of
+ * some 280 workgroups otherwise -- each a little more than one round on 256 CUs, each with its own tail. */
+template <int MODE>
+__global__ __launch_bounds__(VOTE_THREADS) void k_vote_group(const oslamk_vote_args *all, uint32_t wgs_per_member)
+{
+    const uint32_t j = blockIdx.x / wgs_per_member;
+    const oslamk_vote_args a = all[j];
+    vote_body<MODE, 0>(a, blockIdx.x - j * wgs_per_member);
+}
 /* k_vote_wide (the re-vote of workgroups whose 16-bit counters overflowed) lives in oslam_vote_wide.hip */
 
 /* --------------------------------------------------------------------------
@@ -928,6 +940,21 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream)
     dim3 grid((unsigned)(((size_t)a->n_launch + 7) / 8 * 8 * a->table.n_slices));
     hipLaunchKernelGGL((a->mode == 0 ? k_vote<0> : k_vote<1>), grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, *a);
     return oslamk_vote_wide(a, stream);             /* the redo list of this launch (oslam_vote_wide.hip) */
+}
+
+int oslamk_vote_group(const oslamk_vote_args *d_all, const oslamk_vote_args *h_all, int nm, void *stream)
+{
+    if (nm <= 0 || h_all[0].n_launch <= 0) return 0;
+    int max_slices = 1;
+    for (int j = 0; j < nm; j++) {
+        if (h_all[j].n_launch != h_all[0].n_launch || h_all[j].mode != h_all[0].mode) return (int)hipErrorInvalidValue;
+        if (h_all[j].table.n_slices > max_slices) max_slices = h_all[j].table.n_slices;
+    }
+    const size_t wgs = ((size_t)h_all[0].n_launch + 7) / 8 * 8 * (size_t)max_slices;
+    if (wgs * (size_t)nm > 0x7fffffffu) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((h_all[0].mode == 0 ? k_vote_group<0> : k_vote_group<1>), dim3((unsigned)(wgs * (size_t)nm)),
+                       dim3(VOTE_THREADS), 0, (hipStream_t)stream, d_all, (uint32_t)wgs);
+    return oslamk_vote_wide_group(d_all, nm, h_all[0].mode, stream);
 }
 
 size_t oslamk_cluster_table_words(int n)

@@ -331,6 +331,36 @@ def test_model_database_shares_the_scene_pass(ppf, oracle, built_lib, synth):
         assert cells_equal(mo.last_cells()[0], single[j][1])
 
 
+@pytest.mark.parametrize("df", [4, 8])
+def test_model_database_group_of_two_slice_models(ppf, built_lib, synth, df):
+    """A group whose members have more than one table slice (2046 model points per slice) and different table layouts:
+    every member addresses its own slices' entries, voted member after member (df 4: 3 504 workgroups each) or in one
+    grid (df 8: 1 760 each, below the bar of run_votes_group).  Poses, peak cells and counters equal the members' own
+    registrations."""
+    ids = [1, 3, 5]
+    clouds = [synth.make_model(k, n) for k, n in zip(ids, (2300, 2100, 2500))]
+    d = synth.d_dist_for(clouds[0][0], 0.05)
+    sp, sn, _ = synth.make_scene(ids, 7000, 2093, instance_points=900, noise_sigma=0.05 * d)
+    sc = ppf.Scene(sp, sn, d_dist=0.0, ref_point_downsample_factor=df)
+    models = [ppf.Model(c[0], c[1], d_dist=d) for c in clouds]
+    single = []
+    for mo in models:
+        T = mo.ppf_lookup(sc, allow_no_votes=True).copy()
+        single.append((T, mo.last_cells()[0], mo.stats["num_votes"], mo.stats["max_count"], mo.stats["num_unique_votes"]))
+    db = ppf.Database(models)
+    assert db.n_groups == 1
+    for _ in range(2):
+        Ts, stats = db.align(sc)
+        for j, mo in enumerate(models):
+            T, cells, votes, mx, nz = single[j]
+            assert (stats[j]["num_votes"], stats[j]["max_count"], stats[j]["num_unique_votes"]) == (votes, mx, nz), j
+            assert cells_equal(mo.last_cells()[0], cells), j
+            assert np.array_equal(Ts[j], T), j
+    db.close()
+    for m in models:
+        m.close()
+
+
 def test_align_multi_on_a_communicator_of_one(ppf, oracle, built_lib, case_small, case_two_slices):
     """oslam_align_multi through RCCL with a world of one rank (all this box has): the all-reduce of the maximum, the
     device-side filter with the global threshold, the all-gather with exact sizes and the pose tail on the union
