@@ -1420,6 +1420,18 @@ static int run_votes_group(scratch_pool *pool, oslam_model *const *ms, int nm, o
     HIPCHK(hipEventRecord(ev[1], st));
     for (j = 0; j < nm; j++) HIPCHK(hipMemcpyAsync(&cnt[j], ms[j]->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (one_grid) {
+        /* the one-grid launch leaves the re-vote of workgroups whose 16-bit counters overflowed to here: a member that
+         * has any (large planes in a small model: next to never) gets its two passes now and its counters again */
+        int again = 0;
+        for (j = 0; j < nm; j++)
+            if (cnt[j].redo_count) {
+                KCHK(oslamk_vote_wide(&pool->h_vargs[j], g_stream));
+                HIPCHK(hipMemcpyAsync(&cnt[j], ms[j]->d_counters, sizeof *cnt, hipMemcpyDeviceToHost, st));
+                again = 1;
+            }
+        if (again) HIPCHK(hipStreamSynchronize(st));
+    }
     for (j = 0; j < nm; j++)
         if (cnt[j].list_overflow) {
             rc = fail(OSLAM_E_DEVICE, cnt[j].list_overflow & 1u

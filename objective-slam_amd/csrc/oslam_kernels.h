@@ -228,9 +228,10 @@ int oslamk_vote(const oslamk_vote_args *a, void *stream);
 /* the two re-vote passes over the launch's redo list (called by oslamk_vote) */
 int oslamk_vote_wide(const oslamk_vote_args *a, void *stream);
 /* the votes of nm models that share the scene pass (a database group) in one grid: d_all[nm] in device memory, h_all the
- * same on the host (every member with the same batch of reference points and the same mode, its own redo list) */
+ * same on the host (every member with the same batch of reference points and the same mode, its own redo list).  The
+ * re-vote passes are not queued here: the caller looks at the members' redo counts and runs oslamk_vote_wide for the
+ * (rare) member that has any */
 int oslamk_vote_group(const oslamk_vote_args *d_all, const oslamk_vote_args *h_all, int nm, void *stream);
-int oslamk_vote_wide_group(const oslamk_vote_args *d_all, int nm, int mode, void *stream);
 
 /* voxel grid (oslam_voxel.hip): out6 = device [n][6] (x y z nx ny nz per voxel); returns a
  * hipError_t, or -1 when the voxel count overflows int32 */

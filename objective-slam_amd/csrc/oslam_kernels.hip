@@ -954,7 +954,7 @@ int oslamk_vote_group(const oslamk_vote_args *d_all, const oslamk_vote_args *h_a
     if (wgs * (size_t)nm > 0x7fffffffu) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((h_all[0].mode == 0 ? k_vote_group<0> : k_vote_group<1>), dim3((unsigned)(wgs * (size_t)nm)),
                        dim3(VOTE_THREADS), 0, (hipStream_t)stream, d_all, (uint32_t)wgs);
-    return oslamk_vote_wide_group(d_all, nm, h_all[0].mode, stream);
+    return (int)hipGetLastError();      /* the caller runs oslamk_vote_wide for the members whose redo list is not empty */
 }
 
 size_t oslamk_cluster_table_words(int n)

@@ -24,33 +24,6 @@ __global__ __launch_bounds__(VOTE_THREADS) void k_vote_wide(oslamk_vote_args a)
     }
 }
 
-/* the same for the members of a database group voted in one grid (k_vote_group): VOTE_WIDE_GROUP_GRID workgroups per member */
-#define VOTE_WIDE_GROUP_GRID 8
-template <int MODE, int PASS>
-__global__ __launch_bounds__(VOTE_THREADS) void k_vote_wide_group(const oslamk_vote_args *all)
-{
-    const uint32_t j = blockIdx.x / VOTE_WIDE_GROUP_GRID;
-    const oslamk_vote_args a = all[j];
-    const uint32_t n = a.counters->redo_count;
-    for (uint32_t i = blockIdx.x - j * VOTE_WIDE_GROUP_GRID; i < n; i += VOTE_WIDE_GROUP_GRID) {
-        vote_body<MODE, PASS>(a, a.redo[i]);
-        __syncthreads();                            /* the LDS of this workgroup is reused by the next entry */
-    }
-}
-
-extern "C" int oslamk_vote_wide_group(const oslamk_vote_args *d_all, int nm, int mode, void *stream)
-{
-    const dim3 grid((unsigned)(VOTE_WIDE_GROUP_GRID * nm));
-    if (mode == 0) {
-        hipLaunchKernelGGL((k_vote_wide_group<0, 1>), grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, d_all);
-        hipLaunchKernelGGL((k_vote_wide_group<0, 2>), grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, d_all);
-    } else {
-        hipLaunchKernelGGL((k_vote_wide_group<1, 1>), grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, d_all);
-        hipLaunchKernelGGL((k_vote_wide_group<1, 2>), grid, dim3(VOTE_THREADS), 0, (hipStream_t)stream, d_all);
-    }
-    return (int)hipGetLastError();
-}
-
 /* both passes over the redo list of the launch that has just been queued on `stream` (almost always empty) */
 extern "C" int oslamk_vote_wide(const oslamk_vote_args *a, void *stream)
 {

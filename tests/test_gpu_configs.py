@@ -433,6 +433,39 @@ def test_counters_beyond_16_bits(ppf, oracle, built_lib, filler):
     assert np.array_equal(T, To)
 
 
+def test_counters_beyond_16_bits_in_a_database_group(ppf, built_lib):
+    """The members of a group of small models vote in one grid, and the re-vote with 32-bit counters is queued
+    afterwards for the members whose workgroups overflowed: two arc models (cells of 2.8e5 votes) and one ordinary
+    model in one group give what each gives alone -- peak cells, counters, pose -- and say that wide passes ran."""
+    rng = np.random.default_rng(5)
+    mp, mn = _arc_cloud(159, rng)
+    sp, sn = _arc_cloud(2999, rng)
+    mp2, mn2 = _arc_cloud(149, rng)
+    op = rng.uniform(-1, 1, (140, 3)).astype(np.float32)
+    on = rng.normal(size=(140, 3)).astype(np.float32)
+    on /= np.linalg.norm(on, axis=1, keepdims=True)
+    d = 0.3
+    sc = ppf.Scene(sp, sn, d_dist=0.0, ref_point_downsample_factor=1500)
+    models = [ppf.Model(a, b, d_dist=d) for a, b in ((mp, mn), (op, on), (mp2, mn2))]
+    single = []
+    for mo in models:
+        T = mo.ppf_lookup(sc, allow_no_votes=True).copy()
+        single.append((T, mo.last_cells()[0], {k: mo.stats[k] for k in ("num_votes", "num_unique_votes", "max_count", "wide_workgroups")}))
+    assert single[0][2]["wide_workgroups"] > 0 and single[0][2]["max_count"] > 4 * 65535
+    db = ppf.Database(models)
+    assert db.n_groups == 1
+    for _ in range(2):
+        Ts, stats = db.align(sc)
+        for j, mo in enumerate(models):
+            T, cells, st = single[j]
+            assert {k: stats[j][k] for k in st} == st, j
+            assert cells_equal(mo.last_cells()[0], cells), j
+            assert np.array_equal(Ts[j], T), j
+    db.close()
+    for m in models:
+        m.close()
+
+
 def test_distances_on_bin_edges(ppf, oracle, built_lib):
     """The scene-key kernels find a pair's distance bin from the hardware's approximate square root and fall
     back to the exact sequence near a bin edge.  Lattice clouds whose spacing IS d_dist (and a third and 1.5 times
