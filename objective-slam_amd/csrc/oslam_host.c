@@ -1573,8 +1573,8 @@ static int cluster_scores_on_device(size_t n, const float *trans, const float *q
 {
     int rc = OSLAM_OK;
     char *d = NULL, *h = NULL;
-    /* pose order: trans [n][3], quat [n][4], cell [n][3]; sorted order: hash [n], quat, trans, votes; out: score */
-    const size_t o_tr = 0, o_q = o_tr + 12 * n, o_c = o_q + 16 * n, o_sh = o_c + 12 * n, o_sq = o_sh + 4 * n,
+    /* pose order: cell [n][3]; sorted order: hash [n], pose index [n], quat, trans, votes; out: score (pose order) */
+    const size_t o_c = 0, o_sh = o_c + 12 * n, o_si = o_sh + 4 * n, o_sq = o_si + 4 * n,
                  o_st = o_sq + 16 * n, o_sw = o_st + 12 * n, o_sc = o_sw + 4 * n, o_tab = o_sc + 4 * n,
                  total = o_tab + 4 * oslamk_cluster_table_words((int)n);
     size_t j;
@@ -1583,12 +1583,11 @@ static int cluster_scores_on_device(size_t n, const float *trans, const float *q
     hipStream_t st = (hipStream_t)g_stream;
     h = (char *)malloc(o_sc);
     if (!h) return OSLAM_E_NOMEM;
-    memcpy(h + o_tr, trans, 12 * n);
-    memcpy(h + o_q, quat, 16 * n);
     memcpy(h + o_c, cell, 12 * n);
     for (j = 0; j < n; j++) {
         const uint32_t o = hash_idx[2 * j + 1];
         ((uint32_t *)(h + o_sh))[j] = hash_idx[2 * j];
+        ((uint32_t *)(h + o_si))[j] = o;
         memcpy(h + o_sq + 16 * j, quat + 4 * o, 16);
         memcpy(h + o_st + 12 * j, trans + 3 * o, 12);
         ((float *)(h + o_sw))[j] = wv[o];
@@ -1608,8 +1607,8 @@ static int cluster_scores_on_device(size_t n, const float *trans, const float *q
     }
     d = g_cur_pool->d_cluster;
     HIPCHK(hipMemcpyAsync(d, h, o_sc, hipMemcpyHostToDevice, st));
-    KCHK(oslamk_cluster_scores((int)n, (const float *)(d + o_tr), (const float *)(d + o_q), (const int *)(d + o_c),
-                               (const uint32_t *)(d + o_sh), (const float *)(d + o_sq), (const float *)(d + o_st),
+    KCHK(oslamk_cluster_scores((int)n, (const int *)(d + o_c), (const uint32_t *)(d + o_sh), (const uint32_t *)(d + o_si),
+                               (const float *)(d + o_sq), (const float *)(d + o_st),
                                (const float *)(d + o_sw), d_dist, use_l1, (float *)(d + o_sc), whole, NULL, (uint32_t *)(d + o_tab), g_stream));
     HIPCHK(hipMemcpyAsync(score, d + o_sc, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -256,15 +256,15 @@ void oslam_dev_cache_release(int dev);
 int oslamk_aos6_to_soa(const float *d_in6, size_t n, float *d_soa, void *stream);
 
 /* clustering scores of n poses (device arrays).  shash[j] = cell hash of the j-th pose in
- * (hash, pose index) order; sq/st/sw = quaternions [n][4], translations [n][3], weighted votes [n]
- * in that order; trans/quat/cell in pose order.  The translation-averaging variant stays on the host. */
-int oslamk_cluster_scores(int n, const float *trans, const float *quat, const int *cell, const uint32_t *shash,
+ * (hash, pose index) order and sidx[j] its pose index; sq/st/sw = quaternions [n][4], translations [n][3], weighted
+ * votes [n] in that order; cell [n][3] in pose order; score [n] in pose order.  The translation-averaging variant stays on the host. */
+int oslamk_cluster_scores(int n, const int *cell, const uint32_t *shash, const uint32_t *sidx,
                           const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
                           float *score, int whole_host, const unsigned long long *whole_dev, uint32_t *table, void *stream);
-/* table: device work space of oslamk_cluster_table_words(n) 32-bit words (the cells of the sorted list, hashed) */
-size_t oslamk_cluster_table_words(int n);
 /* whole_host / whole_dev: the weighted votes are whole numbers with a sum below 2^24 - 1 (their float sum is then exact
  * in any order and the kernel adds them lane-parallel); whole_dev, if not NULL, points to {sum, not-whole flag} on the device */
+/* table: device work space of oslamk_cluster_table_words(n) 32-bit words (the cells of the sorted list, hashed) */
+size_t oslamk_cluster_table_words(int n);
 
 /* pose tail on the device (oslam_posegpu.hip): filter, order, poses, clustering scores, winner.
  * d_Tm16 [M][16] / d_Ts16 [ceil(S/df)][16]: the frames T_g of the model points and of the scene's

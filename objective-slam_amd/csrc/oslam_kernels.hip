@@ -696,21 +696,27 @@ __global__ void k_cell_table_end(const uint32_t *shash, int n, uint32_t *tab, ui
     }
 }
 
-/* One wave per pose.  Lane c < 27 looks the neighbour cell c up in the table (the reference's (dx, dy, dz) order =
- * ascending c; the pose's own cell is skipped, kernel.cu:684-689); the poses of the 26 cells then form one list,
- * cell after cell, which the 64 lanes test 64 at a time -- a handful of independent loads per pose instead of 26
- * binary searches and 26 dependent cell walks (with 5 * 10^4 poses per model of the depth-stream database the kernel
- * sat at the latency of those chains: 0.5 ms per model).  The compatible ones are added by walking the ballot mask in
- * ascending order, i.e. exactly the sequential float sum of the reference loop -- or, when the weighted votes are
- * whole numbers with a small sum, lane-parallel (see `whole`).  sq/st/sw are the pose quaternions, translations and
- * weighted votes permuted into sorted (cell hash, pose index) order, so consecutive lanes read consecutive memory. */
-__global__ __launch_bounds__(64) void k_cluster_scores(int n, const float *trans, const float *quat,
-                                                       const int *cell, const uint32_t *tab, uint32_t mask,
+/* One wave per FOUR consecutive poses of the sorted list.  Lane c < 27 looks the neighbour cell c up in the table (the
+ * reference's (dx, dy, dz) order = ascending c; the pose's own cell is skipped, kernel.cu:684-689); the poses of the 26
+ * cells then form one list, cell after cell, which the 64 lanes test 64 at a time, four rounds' loads in flight -- a
+ * handful of independent loads per pose instead of 26 binary searches and 26 dependent cell walks (with 5 * 10^4 poses
+ * per model of the depth-stream database the kernel sat at the latency of those chains: 0.5 ms per model).
+ *
+ * The compatible poses are added by walking the ballot mask in ascending order, i.e. exactly the sequential float sum
+ * of the reference loop -- or, when the weighted votes are whole numbers with a small sum (`whole`), lane-parallel.  In
+ * that case the wave's poses that lie in one cell (neighbours in the sorted list) also SHARE the walk: they have the
+ * same 26 neighbour cells, so a candidate is loaded once and tested against up to four poses -- a dense cluster (an
+ * instance in the scene: 10^4 poses in a few cells, every one walking all the others) is bound by the candidates'
+ * bytes from L2, not by the tests.  sq/st/sw are the pose quaternions, translations and weighted votes in sorted
+ * (cell hash, pose index) order, sidx the pose index of a sorted position, cell the cell coordinates in pose order. */
+__global__ __launch_bounds__(64) void k_cluster_scores(int n, const int *cell, const uint32_t *shash, const uint32_t *sidx,
+                                                       const uint32_t *tab, uint32_t mask,
                                                        const float4 *sq, const float *st, const float *sw,
-                                                       float d_dist, int use_l1, float *score, int whole_host,
+                                                       float dist2_below, int use_l1, float *score, int whole_host,
                                                        const unsigned long long *whole_dev)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t p0 = 4u * blockIdx.x, un = (uint32_t)n;
     /* Weighted votes that are all whole numbers and sum to less than 2^24 (weights of 1, the default: the votes are
      * counts) add up exactly in float whatever the order: every partial sum is a whole number below 2^24.  Then the
      * lanes keep their own sums and the wave adds them once -- the same bits as the reference's sequential sum, without
@@ -718,101 +724,133 @@ __global__ __launch_bounds__(64) void k_cluster_scores(int n, const float *trans
      * host-made input (whole_host) or by k_pose_cells on the device (whole_dev[0] = sum of the votes, [1] != 0: one
      * of them is not whole). */
     const bool whole = whole_dev ? (whole_dev[1] == 0ull && whole_dev[0] < (1ull << 24) - 1ull) : whole_host != 0;
-    float lane_sum = 0.0f;
     const float rot_thresh = 2 * PM_D_ANGLE, rot_thresh_sq = rot_thresh * rot_thresh;
-    const float q0 = quat[4 * i], q1 = quat[4 * i + 1], q2 = quat[4 * i + 2], q3 = quat[4 * i + 3];
-    const float tx = trans[3 * i], ty = trans[3 * i + 1], tz = trans[3 * i + 2];
-    const int cx = cell[3 * i], cy = cell[3 * i + 1], cz = cell[3 * i + 2];
-    float votes = 1;                                             /* kernel.cu:722 */
-    uint32_t first = 0, len = 0;
-    if (lane < 27 && lane != 13) {
-        const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
-        const uint32_t h = fnv_cell3(cx + dx, cy + dy, cz + dz);
-        if (h != 0u) {                                            /* a hash of 0 is never searched (kernel.cu:727) */
-            for (uint32_t s = cell_slot(h, mask);; s = (s + 1u) & mask) {
-                const uint32_t k = tab[3u * s];
-                if (k == h) {
-                    first = tab[3u * s + 1u];
-                    const uint32_t end = tab[3u * s + 2u];
-                    len = end > first && end <= (uint32_t)n ? end - first : 0u;
-                    break;
+    for (uint32_t g0 = 0; g0 < 4u && p0 + g0 < un;) {
+        /* the group: this position and, in whole mode, the following ones of the wave that lie in the same cell */
+        const uint32_t pa = p0 + g0, oa = uni_u32(sidx[pa]), ha = uni_u32(shash[pa]);
+        const int cx = (int)uni_u32((uint32_t)cell[3 * oa]), cy = (int)uni_u32((uint32_t)cell[3 * oa + 1]),
+                  cz = (int)uni_u32((uint32_t)cell[3 * oa + 2]);
+        uint32_t G = 1;
+        if (whole)
+            while (g0 + G < 4u && pa + G < un) {
+                const uint32_t ob = uni_u32(sidx[pa + G]);
+                if (uni_u32(shash[pa + G]) != ha || cell[3 * ob] != cx || cell[3 * ob + 1] != cy || cell[3 * ob + 2] != cz) break;
+                G++;
+            }
+        float q0[4], q1[4], q2[4], q3[4], tx[4], ty[4], tz[4], lane_sum[4];
+        uint32_t orig[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                             /* members past the group's end repeat its last one; their sums are dropped */
+            const uint32_t pk = pa + ((uint32_t)k < G ? (uint32_t)k : G - 1u);
+            const float4 qq = sq[pk];
+            q0[k] = qq.x; q1[k] = qq.y; q2[k] = qq.z; q3[k] = qq.w;
+            tx[k] = st[3 * pk]; ty[k] = st[3 * pk + 1]; tz[k] = st[3 * pk + 2];
+            orig[k] = sidx[pk];
+            lane_sum[k] = 0.0f;
+        }
+        float votes = 1;                                          /* kernel.cu:722 (the sequential path: G == 1) */
+        uint32_t first = 0, len = 0;
+        if (lane < 27 && lane != 13) {
+            const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
+            const uint32_t h = fnv_cell3(cx + dx, cy + dy, cz + dz);
+            if (h != 0u) {                                        /* a hash of 0 is never searched (kernel.cu:727) */
+                for (uint32_t s = cell_slot(h, mask);; s = (s + 1u) & mask) {
+                    const uint32_t k = tab[3u * s];
+                    if (k == h) {
+                        first = tab[3u * s + 1u];
+                        const uint32_t end = tab[3u * s + 2u];
+                        len = end > first && end <= un ? end - first : 0u;
+                        break;
+                    }
+                    if (k == 0u) break;
                 }
-                if (k == 0u) break;
             }
         }
-    }
-    uint32_t incl = len;                                          /* running sums over the 27 lanes */
-    for (int o = 1; o < 32; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += up;
-    }
-    const uint32_t excl = incl - len, total = readlane_u(incl, 26);
-    uint32_t c0 = 0;                                              /* scalar: the cell that holds the list position being placed */
-    /* Four times 64 list positions per round, all their loads issued before the first test: a pose in a dense cluster
-     * walks thousands of candidates, and with one load round trip per 64 of them the kernel's time was the longest such
-     * walk (1.4 ms per model on the 4-model depth stream), not its work. */
-    for (uint32_t base = 0; base < total; base += 4u * WAVE) {
-        uint32_t j[4];
-        bool in[4];
+        uint32_t incl = len;                                      /* running sums over the 27 lanes */
+        for (int o = 1; o < 32; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
+        }
+        const uint32_t excl = incl - len, total = readlane_u(incl, 26);
+        uint32_t c0 = 0;                                          /* scalar: the cell that holds the list position being placed */
+        /* Four times 64 list positions per round, all their loads issued before the first test. */
+        for (uint32_t base = 0; base < total; base += 4u * WAVE) {
+            uint32_t j[4];
+            bool in[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t b = base + (uint32_t)u * WAVE, f = b + (uint32_t)lane;
-            in[u] = f < total;
-            j[u] = 0;
-            if (b >= total) continue;                             /* wave-uniform */
-            while (readlane_u(incl, (int)c0) <= b) c0++;          /* b < total = incl[26]: stops at 26 at the latest */
-            uint32_t cf, ce;
-            if (b + WAVE <= readlane_u(incl, (int)c0)) {          /* the 64 positions lie in one cell: the usual case in a dense cluster */
-                cf = readlane_u(first, (int)c0);
-                ce = readlane_u(excl, (int)c0);
-            } else {
-                uint32_t c = 0;                                   /* the cell of list position f: running sum <= f */
+            for (int u = 0; u < 4; u++) {
+                const uint32_t b = base + (uint32_t)u * WAVE, f = b + (uint32_t)lane;
+                in[u] = f < total;
+                j[u] = 0;
+                if (b >= total) continue;                         /* wave-uniform */
+                while (readlane_u(incl, (int)c0) <= b) c0++;      /* b < total = incl[26]: stops at 26 at the latest */
+                uint32_t cf, ce;
+                if (b + WAVE <= readlane_u(incl, (int)c0)) {      /* the 64 positions lie in one cell: the usual case in a dense cluster */
+                    cf = readlane_u(first, (int)c0);
+                    ce = readlane_u(excl, (int)c0);
+                } else {
+                    uint32_t c = 0;                               /* the cell of list position f: running sum <= f */
 #pragma unroll
-                for (uint32_t s2 = 16; s2 > 0; s2 >>= 1) {
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c + s2 - 1u) << 2), (int)incl);
-                    c += v <= f ? s2 : 0u;
+                    for (uint32_t s2 = 16; s2 > 0; s2 >>= 1) {
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((c + s2 - 1u) << 2), (int)incl);
+                        c += v <= f ? s2 : 0u;
+                    }
+                    c = c < 26u ? c : 26u;
+                    cf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)first);
+                    ce = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)excl);
                 }
-                c = c < 26u ? c : 26u;
-                cf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)first);
-                ce = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)excl);
+                j[u] = in[u] ? cf + (f - ce) : 0u;
             }
-            j[u] = in[u] ? cf + (f - ce) : 0u;
-        }
-        float4 qo[4];
-        float ex[4], ey[4], ez[4], w[4];
+            float4 qo[4];
+            float ex[4], ey[4], ez[4], w[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {                             /* position 0 for the lanes past the end: loaded, not used */
-            qo[u] = sq[j[u]];
-            ex[u] = st[3 * j[u]];
-            ey[u] = st[3 * j[u] + 1];
-            ez[u] = st[3 * j[u] + 2];
-            w[u] = sw[j[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float qd = fabsf(8 * (1 - (q0 * qo[u].x + q1 * qo[u].y + q2 * qo[u].z + q3 * qo[u].w)));
-            bool ok = in[u] && qd < rot_thresh_sq;
-            if (ok && !use_l1) {
-                const float dx = tx - ex[u], dy = ty - ey[u], dz = tz - ez[u];
-                ok = pm_sqrtf(dx * dx + dy * dy + dz * dz) < d_dist;
+            for (int u = 0; u < 4; u++) {                         /* position 0 for the lanes past the end: loaded, not used */
+                qo[u] = sq[j[u]];
+                ex[u] = st[3 * j[u]];
+                ey[u] = st[3 * j[u] + 1];
+                ez[u] = st[3 * j[u] + 2];
+                w[u] = sw[j[u]];
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((uint32_t)k >= G) continue;               /* wave-uniform */
+                    const float qd = fabsf(8 * (1 - (q0[k] * qo[u].x + q1[k] * qo[u].y + q2[k] * qo[u].z + q3[k] * qo[u].w)));
+                    bool ok = in[u] && qd < rot_thresh_sq;
+                    if (ok && !use_l1) {
+                        /* sqrt(x) < d_dist with the correctly rounded, monotonic sqrt of the reference's sequence is
+                         * x < dist2_below, the smallest float whose root reaches d_dist (made by the launcher): the same
+                         * answer for every x, without a root per pair */
+                        const float dx = tx[k] - ex[u], dy = ty[k] - ey[u], dz = tz[k] - ez[u];
+                        ok = dx * dx + dy * dy + dz * dz < dist2_below;
+                    }
+                    if (whole) {
+                        lane_sum[k] += ok ? w[u] : 0.0f;
+                    } else {                                      /* G == 1 */
+                        unsigned long long m = __ballot(ok);
+                        while (m) {                               /* ascending list position: the reference's order */
+                            const int b = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            votes += readlane_f(w[u], b);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((uint32_t)k >= G) continue;
+            float v = votes;
             if (whole) {
-                lane_sum += ok ? w[u] : 0.0f;
-            } else {
-                unsigned long long m = __ballot(ok);
-                while (m) {                                      /* ascending list position: the reference's order */
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    votes += readlane_f(w[u], b);
-                }
+                float s = lane_sum[k];
+                for (int o = WAVE / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+                v = 1 + s;
             }
+            if (lane == 0) score[orig[k]] = v;
         }
+        g0 += G;
     }
-    if (whole) {
-        for (int o = WAVE / 2; o > 0; o >>= 1) lane_sum += __shfl_xor(lane_sum, o, WAVE);
-        votes += lane_sum;
-    }
-    if (lane == 0) score[i] = votes;
 }
 
 /* --------------------------------------------------------------------------
@@ -964,7 +1002,7 @@ size_t oslamk_cluster_table_words(int n)
     return 3u * (size_t)cap;
 }
 
-int oslamk_cluster_scores(int n, const float *trans, const float *quat, const int *cell, const uint32_t *shash,
+int oslamk_cluster_scores(int n, const int *cell, const uint32_t *shash, const uint32_t *sidx,
                           const float *sq, const float *st, const float *sw, float d_dist, int use_l1,
                           float *score, int whole_host, const unsigned long long *whole_dev, uint32_t *table, void *stream)
 {
@@ -975,8 +1013,28 @@ int oslamk_cluster_scores(int n, const float *trans, const float *quat, const in
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_cell_table_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, shash, n, table, mask);
     hipLaunchKernelGGL(k_cell_table_end, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, (hipStream_t)stream, shash, n, table, mask);
-    hipLaunchKernelGGL(k_cluster_scores, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, n, trans, quat, cell,
-                       table, mask, reinterpret_cast<const float4 *>(sq), st, sw, d_dist, use_l1, score, whole_host, whole_dev);
+    /* the smallest float x with pm_sqrtf(x) >= d_dist: pm_sqrtf is correctly rounded, hence monotonic, so
+     * pm_sqrtf(x) < d_dist  <=>  x < dist2_below for every float x (a NaN fails both) */
+    float dist2_below = d_dist * d_dist;
+    {
+        uint32_t b;
+        __builtin_memcpy(&b, &dist2_below, sizeof b);
+        if (d_dist > 0.0f && b > 0x00800000u && b < 0x7f000000u) {
+            float x = dist2_below;
+            for (int it = 0; it < 8 && pm_sqrtf(x) >= d_dist; it++) { b--; __builtin_memcpy(&x, &b, sizeof x); }
+            for (int it = 0; it < 16 && pm_sqrtf(x) < d_dist; it++) { b++; __builtin_memcpy(&x, &b, sizeof x); }
+            dist2_below = x;
+            /* checked, not assumed: the neighbours of the threshold fall on the right sides */
+            uint32_t lo = b - 1u;
+            float xl;
+            __builtin_memcpy(&xl, &lo, sizeof xl);
+            if (!(pm_sqrtf(x) >= d_dist) || !(pm_sqrtf(xl) < d_dist)) return (int)hipErrorInvalidValue;
+        } else {
+            return (int)hipErrorInvalidValue;       /* d_dist not a normal positive number: no clustering radius */
+        }
+    }
+    hipLaunchKernelGGL(k_cluster_scores, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, (hipStream_t)stream, n, cell, shash, sidx,
+                       table, mask, reinterpret_cast<const float4 *>(sq), st, sw, dist2_below, use_l1, score, whole_host, whole_dev);
     return (int)hipGetLastError();
 }
 

@@ -409,7 +409,7 @@ extern "C" int oslamk_pose_finish_async(uint32_t n, const oslamk_cell *d_sel, co
         /* (cell key, index) ascending: indices are ascending already and the sort is stable */
         PCHK(rocprim::radix_sort_pairs(d_tmp, tmp_s32, hash, shash, idx, sidx, (size_t)n, 0, 32, stream));
         hipLaunchKernelGGL(k_pose_gather, dim3(blocks), dim3(256), 0, stream, sidx, n, quat, trans, wv, sq, st, sw);
-        rc = oslamk_cluster_scores((int)n, trans, quat, cell, shash, sq, st, sw, d_dist, use_l1, score, 0, whole,
+        rc = oslamk_cluster_scores((int)n, cell, shash, sidx, sq, st, sw, d_dist, use_l1, score, 0, whole,
                                    (uint32_t *)(d + c.tab), stream_);
         if (rc != 0) goto done;
         hipLaunchKernelGGL(k_pose_best, dim3(bb), dim3(1024), 0, stream, score, n, d_poses, trans, d_best,
